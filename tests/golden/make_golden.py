@@ -1,0 +1,316 @@
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE's own Python.
+
+Run in the build container only (it needs /root/reference):
+    python tests/golden/make_golden.py
+The reference never travels to the GPU box; only the .npz files written here do.
+
+What is imported from the reference, unmodified:
+  data_creator/render_wt_pt_proj/pt2render.py            -> ref_a  (variant A visibility)
+  data_creator/render_wt_pt_proj/variables.py            -> constants
+  classifier_code/train_test_scripts/utils/pt2render.py  -> ref_b  (variant B visibility)
+  classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py -> CorrelationMapLayer.forward,
+      called unbound on CPU with a stub `self` that only carries `down1` (the class
+      constructor calls .cuda()).
+What cannot be imported here (cv2 / trimesh / OpenEXR / caffe missing) and is therefore
+re-typed below on top of the imported primitives, following the cited lines:
+  run_proj.get_3d_to_2d / prune_pts (run_proj.py:24-46), make_disparity's body
+  (make_disparity_syn.py:44-68), io_utils.get_render_array / get_pt_depth_map
+  (io_utils.py:97-124).
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_a = _load("ref_pt2render_a", f"{REF}/data_creator/render_wt_pt_proj/pt2render.py")
+ref_vars = _load("ref_variables", f"{REF}/data_creator/render_wt_pt_proj/variables.py")
+ref_b = _load("ref_pt2render_b", f"{REF}/classifier_code/train_test_scripts/utils/pt2render.py")
+
+ANCHOR_FILES = {
+    "bed": "02818832/7c8eb4ab1f2c8bfa2fb46fb8b9b1ac9f",
+    "chair": "03001627/13fdf00cde077f562f6f52615fb75fca",
+    "sofa_b": "04256520/2bb1b5865455b2b814513156cf2b8d0d",
+    "sofa": "04256520/1fd45c57ab27cb6cea65c47b660136e7",
+    "table": "04379243/e41da371550711697062f2d72cde5c95",
+}
+
+
+def load_anchors():
+    return {k: np.loadtxt(f"{REF}/classifier_code/anchors/{v}/anchors.txt", delimiter=" ")
+            for k, v in ANCHOR_FILES.items()}
+
+
+def load_obj_vertices():
+    path = f"{REF}/data_creator/render_wt_pt_proj/02818832/42e4e91343b44d77c3bd24f986301745/model.obj"
+    if not os.path.exists(path):
+        import glob
+        path = glob.glob(f"{REF}/data_creator/render_wt_pt_proj/02818832/*/model.obj")[0]
+    verts = []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("v "):
+                verts.append([float(t) for t in line.split()[1:4]])
+    return np.array(verts)
+
+
+# ---- re-typed orchestration (see module docstring) -------------------------------------
+def ref_get_3d_to_2d(ref, model_pts, params):          # run_proj.py:24-31
+    e = ref.ex_camera_matrix(params[0], params[1], params[2], params[3])
+    cam = ref.get_camera_matrix(ref_vars.INTRINSIC_CAMERA_MATRIX, e, ref_vars.WORLD_MATRIX)
+    return ref.get_render_location(model_pts, cam)
+
+
+def ref_prune_pts(pt_array, depth_map, crop=False, crop_params=None):   # run_proj.py:33-46
+    depth_truth, depth_pt_array = ref_a.depth_visibility_array(pt_array, depth_map)
+    if crop:
+        crop_truth, crop_pt_array = ref_a.crop_visibility_array(pt_array, crop_params)
+    else:
+        crop_truth = np.ones(depth_truth.shape)
+        crop_pt_array = depth_pt_array
+    return crop_truth * depth_truth, crop_pt_array
+
+
+def ref_make_disparity_body(key_3d, params, depth_map, crop_params):    # make_disparity_syn.py:44-68
+    params = list(params)
+    key_2d_norm = ref_get_3d_to_2d(ref_a, key_3d, params)
+    truth_1, key_2d = ref_prune_pts(key_2d_norm, depth_map, crop=True, crop_params=crop_params)
+    params[0] += 10
+    params[1] += 10
+    key_2d_more = ref_get_3d_to_2d(ref_a, key_3d, params)
+    truth_2, key_2d = ref_prune_pts(key_2d_more, depth_map, crop=True, crop_params=crop_params)
+    truth = truth_1.astype('bool')
+    key_2d_more = np.copy(key_2d_more[:, truth])
+    key_2d_norm = np.copy(key_2d_norm[:, truth])
+    del_azi = key_2d_more - key_2d_norm
+    flow = np.zeros((224, 224, 2))
+    k = 2
+    for i in range(key_2d_norm.shape[1]):
+        pt = key_2d_norm[:, i][:2].astype(int)
+        flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 0] = del_azi[:, i][0]
+        flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 1] = del_azi[:, i][1]
+    return flow, truth_1, truth_2
+
+
+def ref_get_render_array(file_dict, model_pts, depth_map):              # io_utils.py:97-117
+    pt_array = ref_get_3d_to_2d(ref_b, model_pts, [file_dict['azimuth'], file_dict['elevation'],
+                                                   file_dict['tilt'], file_dict['rho']])
+    depth_truth, depth_pt_array = ref_b.depth_visibility_array(pt_array, depth_map)
+    crop_truth, crop_pt_array = ref_b.crop_visibility_array(pt_array, file_dict['crop_params'])
+    return crop_truth * depth_truth, crop_pt_array
+
+
+def ref_get_pt_depth_map(render_array, size=(540, 960), radius=2):      # io_utils.py:119-124
+    depth_map = np.zeros(size)
+    for i in range(render_array.shape[1]):
+        depth_map[int(render_array[1, i]) - radius:int(render_array[1, i]) + radius,
+                  int(render_array[0, i]) - radius:int(render_array[0, i]) + radius] = render_array[2, i]
+    return depth_map
+
+
+# ---- synthetic inputs --------------------------------------------------------------------
+def surface_depth_map(pt_render, background=20.0):
+    """A plausible depth image for these points: nearest z per pixel, dilated by 2 px."""
+    from oracle import zbuffer as zb
+    _, _, depth = zb.zbuffer(pt_render, 540, 960, radius=2)
+    depth = depth.copy()
+    depth[~np.isfinite(depth)] = background
+    return depth.astype(np.float32)
+
+
+def bbox_crop(pt_render, truth):
+    u, v = pt_render[0, truth], pt_render[1, truth]
+    return [int(v.min()) - 3, int(v.max()) + 3, int(u.min()) - 3, int(u.max()) + 3]
+
+
+def gen_geometry():
+    out = {}
+    # G1 cameras
+    poses = [(az, el, t, rho) for az in range(0, 360, 30) for el in (-10, 0, 10, 45)
+             for t in (-10, 0, 10) for rho in (2, 3)]
+    poses += [(33.25, 12.5, -7.75, 2.5), (359.999, 89.0, 25.0, 3.75)]
+    out["g1_poses"] = np.array(poses, dtype=np.float64)
+    out["g1_E"] = np.stack([ref_a.ex_camera_matrix(*p) for p in poses])
+    out["g1_P"] = np.stack([ref_a.get_camera_matrix(ref_vars.INTRINSIC_CAMERA_MATRIX, e,
+                                                    ref_vars.WORLD_MATRIX) for e in out["g1_E"]])
+    out["g1_R"] = np.stack([ref_a.rot_three_angles(p[0], p[1], p[2]) for p in poses])
+    # G2 projection
+    anchors = load_anchors()
+    cam = out["g1_P"][poses.index((30, 10, 0, 3))]
+    for name, a in anchors.items():
+        out[f"g2_anchor_{name}"] = a
+        out[f"g2_anchor_{name}_render"] = ref_a.get_render_location(a, cam)
+    verts = load_obj_vertices()
+    out["g2_obj_vertices"] = verts
+    out["g2_obj_render"] = ref_a.get_render_location(verts, cam)
+    big = np.random.RandomState(0).uniform(-0.4, 0.4, (100000, 3))
+    big_render = ref_a.get_render_location(big, cam)
+    sub = np.arange(0, 100000, 25)
+    out["g2_big_cam"] = cam
+    out["g2_big_sub_index"] = sub
+    out["g2_big_sub_render"] = big_render[:, sub]
+    out["g2_big_uv_sha256"] = np.frombuffer(
+        hashlib.sha256(np.ascontiguousarray(big_render[:2]).tobytes()).digest(), dtype=np.uint8)
+    # G3 visibility A / B
+    pts = np.random.RandomState(1).uniform(-0.45, 0.45, (6000, 3))
+    # a pose/distance that pushes some points outside the frame and into x in [950, 960)
+    for tag, params in (("near", [30.0, 10.0, 0.0, 1.1]), ("std", [30.0, 10.0, 0.0, 3.0]),
+                        ("tilt", [200.0, -5.0, 12.0, 2.0])):
+        r = ref_get_3d_to_2d(ref_a, pts, params)
+        depth_surface = surface_depth_map(r)
+        depth_const = np.full((540, 960), 3.0, dtype=np.float32)
+        yy, xx = np.mgrid[0:540, 0:960]
+        depth_plane = (params[3] - 0.3 + 0.0006 * xx + 0.0004 * yy).astype(np.float32)
+        out[f"g3_{tag}_params"] = np.array(params)
+        out[f"g3_{tag}_pts"] = pts
+        out[f"g3_{tag}_render"] = r
+        for dname, d in (("surface", depth_surface), ("const", depth_const), ("plane", depth_plane)):
+            ta, ra = ref_a.depth_visibility_array(r.copy(), d)
+            tb, rb = ref_b.depth_visibility_array(r.copy(), d)
+            if dname != "const":
+                out[f"g3_{tag}_depth_{dname}"] = d
+            out[f"g3_{tag}_{dname}_truth_a"] = ta
+            out[f"g3_{tag}_{dname}_truth_b"] = tb
+            out[f"g3_{tag}_{dname}_pruned_b"] = rb
+    # exact-threshold cases: z chosen so |z - d| sits exactly on / next to the relaxation
+    d = np.full((540, 960), 2.5, dtype=np.float32)
+    d[100, 200] = np.float32(2.3)
+    edge = np.array([[200, 200, 200, 200, 200, 200, 949, 950, 0, 1, 1, 300],
+                     [100, 100, 100, 100, 100, 100, 539, 10, 10, 0, 1, 540],
+                     [2.45, np.nextafter(2.45, 3), 2.15, np.nextafter(2.15, 0),
+                      float(np.float32(2.3)) + 0.15, float(np.float32(2.3)) - 0.15,
+                      2.5, 2.5, 2.5, 2.5, 2.5, 2.5]], dtype=np.float64)
+    out["g3_edge_depth"] = d
+    out["g3_edge_render"] = edge
+    out["g3_edge_truth_a"] = ref_a.depth_visibility_array(edge.copy(), d)[0]
+    out["g3_edge_truth_b"] = ref_b.depth_visibility_array(edge.copy(), d)[0]
+    # G4 crop remap (tall, wide, square crops; aliasing)
+    r = out["g3_std_render"]
+    for tag, crop in (("wide", [100, 400, 300, 700]), ("tall", [50, 500, 400, 600]),
+                      ("square", [120, 420, 330, 630]), ("odd", [101, 388, 297, 641])):
+        arr = r.copy()
+        t, same = ref_a.crop_visibility_array(arr, crop)
+        assert same is arr
+        out[f"g4_{tag}_crop"] = np.array(crop)
+        out[f"g4_{tag}_truth"] = t
+        out[f"g4_{tag}_render"] = arr
+    arr = r.copy()
+    t, _ = ref_a.crop_visibility_array(arr, [100, 400, 300, 700], resize=False)
+    out["g4_noresize_truth"] = t
+    out["g4_noresize_render"] = arr
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+    print("geometry.npz", len(out), "arrays")
+
+
+def gen_disparity():
+    out = {}
+    anchors = load_anchors()
+    verts = load_obj_vertices()
+    rs = np.random.RandomState(7)
+    cloud = rs.uniform(-0.35, 0.35, (5000, 3))
+    # surface-like cloud: jittered copies of the bed mesh vertices
+    mesh_cloud = verts[rs.randint(0, len(verts), 4000)] + rs.normal(0, 0.002, (4000, 3))
+    for tag, pts, params in (("cloud", cloud, [30.0, 10.0, 0.0, 3.0]),
+                             ("mesh", mesh_cloud, [135.0, 20.0, -5.0, 2.5]),
+                             ("edge", cloud, [300.0, 0.0, 0.0, 1.4])):
+        r = ref_get_3d_to_2d(ref_a, pts, params)
+        depth = surface_depth_map(r)
+        t, _ = ref_a.depth_visibility_array(r.copy(), depth)
+        crop = bbox_crop(r, t)
+        if tag == "edge":      # a crop that cuts through the object: points land on the border
+            crop = [crop[0] + 40, crop[1] - 25, crop[2] + 60, crop[3] - 10]
+        flow, t1, t2 = ref_make_disparity_body(pts, params, depth, crop)
+        out[f"{tag}_pts"] = pts
+        out[f"{tag}_params"] = np.array(params)
+        out[f"{tag}_depth"] = depth
+        out[f"{tag}_crop"] = np.array(crop)
+        out[f"{tag}_flow"] = flow
+        out[f"{tag}_truth_1"] = t1
+        out[f"{tag}_truth_2"] = t2
+    # variant-B pipeline (get_render_array) and point depth splat on the shipped anchors
+    for name, a in anchors.items():
+        fd = {"azimuth": 120.0, "elevation": 10.0, "tilt": 0.0, "rho": 2.2,
+              "crop_params": [60, 480, 250, 720]}
+        dense = np.concatenate([a, verts[::7]], axis=0)
+        r = ref_get_3d_to_2d(ref_b, dense, [120.0, 10.0, 0.0, 2.2])
+        depth = surface_depth_map(r)
+        truth, crop_pts = ref_get_render_array(fd, a, depth)
+        out[f"rb_{name}_depth"] = depth
+        out[f"rb_{name}_truth"] = truth
+        out[f"rb_{name}_crop_pts"] = crop_pts
+    r = ref_get_3d_to_2d(ref_a, cloud[:600], [30.0, 10.0, 0.0, 3.0])
+    out["ptdepth_render"] = r
+    out["ptdepth_map"] = ref_get_pt_depth_map(r)
+    np.savez_compressed(os.path.join(HERE, "disparity.npz"), **out)
+    print("disparity.npz", len(out), "arrays")
+
+
+def gen_correlation():
+    import torch
+    sys.path.insert(0, f"{REF}/classifier_code")
+    # eccv_net.py imports configs.constants (a pure-python constants module) and the sibling
+    # loss / googlenet modules; all import cleanly on CPU.
+    pkg = "train_test_scripts.arch.eccv_net.eccv_net"
+    try:
+        eccv = importlib.import_module(pkg)
+    except Exception as exc:             # pragma: no cover - depends on the container
+        print("cannot import the reference eccv_net:", repr(exc))
+        raise
+    stub = types.SimpleNamespace(down1=torch.nn.UpsamplingBilinear2d(size=(28, 28)))
+    out = {}
+    rs = np.random.RandomState(11)
+    cases = {"b1k1": (1, 1, 128), "b2k10": (2, 10, 32), "b3k14": (3, 14, 8)}
+    for tag, (b, k, c) in cases.items():
+        f1 = rs.randn(b, c, 56, 56).astype(np.float32)
+        f2 = rs.randn(b, c, 56, 56).astype(np.float32)
+        f1 /= np.sqrt((f1 ** 2).sum(1, keepdims=True))
+        f2 /= np.sqrt((f2 ** 2).sum(1, keepdims=True))
+        knn = rs.randint(0, 28, (k, 2)).astype(np.int64)
+        knn[0] = [0, 27]
+        if k > 1:
+            knn[1] = [27, 0]
+        with torch.no_grad():
+            res = eccv.CorrelationMapLayer.forward(stub, torch.from_numpy(f1), torch.from_numpy(f2),
+                                                   torch.from_numpy(knn))
+        res = res.data if hasattr(res, "data") else res
+        out[f"{tag}_f1"] = f1.astype(np.float16)     # stored compactly; tests upcast the SAME way
+        out[f"{tag}_f2"] = f2.astype(np.float16)
+        out[f"{tag}_knn"] = knn
+        # rerun on the float16-rounded inputs so the stored inputs are the exact inputs
+        f1r = out[f"{tag}_f1"].astype(np.float32)
+        f2r = out[f"{tag}_f2"].astype(np.float32)
+        with torch.no_grad():
+            res = eccv.CorrelationMapLayer.forward(stub, torch.from_numpy(f1r), torch.from_numpy(f2r),
+                                                   torch.from_numpy(knn))
+        out[f"{tag}_out"] = np.asarray(res.data if hasattr(res, "data") else res)
+    # the resize alone (torch's own kernel, the same call the reference makes)
+    x = rs.randn(2, 3, 56, 56).astype(np.float32)
+    out["resize_in"] = x
+    out["resize_out"] = stub.down1(torch.from_numpy(x)).numpy()
+    np.savez_compressed(os.path.join(HERE, "correlation.npz"), **out)
+    print("correlation.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["geometry", "disparity", "correlation"]
+    if "geometry" in which:
+        gen_geometry()
+    if "disparity" in which:
+        gen_disparity()
+    if "correlation" in which:
+        gen_correlation()

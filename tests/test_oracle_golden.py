@@ -1,0 +1,236 @@
+"""CPU: the oracle restatement against golden vectors produced by the imported reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import cnative, correlation, disparity, geometry as g, keypoints as kp, nn, zbuffer
+
+ANCHORS = ["bed", "chair", "sofa_b", "sofa", "table"]
+
+
+def test_camera_matrices(golden_geometry):
+    z = golden_geometry
+    for pose, e, p, r in zip(z["g1_poses"], z["g1_E"], z["g1_P"], z["g1_R"]):
+        assert np.array_equal(g.rot_three_angles(pose[0], pose[1], pose[2]), r)
+        assert np.array_equal(g.ex_camera_matrix(*pose), e)
+        assert np.array_equal(g.camera_from_params(pose), p)
+
+
+def test_survey_known_answer():
+    e = g.ex_camera_matrix(30, 10, 0, 3)
+    assert np.allclose(e[2], [-0.85286853, -0.49240388, -0.17364818, 3.0], atol=1e-8)
+    p = g.camera_from_params([30, 10, 0, 3])
+    pts = np.random.RandomState(0).uniform(-0.4, 0.4, (5, 3))
+    r = g.get_render_location(pts, p)
+    assert r[0].tolist() == [448., 439., 382., 489., 584.]
+    assert r[1].tolist() == [210., 289., 155., 185., 155.]
+    t, rc = g.crop_visibility_array(r.copy(), [100, 400, 300, 700])
+    assert t.all() and rc[0].tolist() == [83., 78., 46., 106., 159.]
+    assert rc[1].tolist() == [90., 134., 59., 76., 59.]
+
+
+@pytest.mark.parametrize("name", ANCHORS)
+def test_projection_anchors(golden_geometry, name):
+    z = golden_geometry
+    cam = z["g2_big_cam"]
+    want = z[f"g2_anchor_{name}_render"]
+    assert np.array_equal(g.get_render_location(z[f"g2_anchor_{name}"], cam), want)
+    assert np.array_equal(cnative.project_fma(z[f"g2_anchor_{name}"], cam), want)
+
+
+def test_projection_mesh_and_cloud(golden_geometry):
+    z = golden_geometry
+    cam = z["g2_big_cam"]
+    assert np.array_equal(g.get_render_location(z["g2_obj_vertices"], cam), z["g2_obj_render"])
+    got_c = cnative.project_fma(z["g2_obj_vertices"], cam)
+    assert np.array_equal(got_c[:2], z["g2_obj_render"][:2])
+    assert np.allclose(got_c[2], z["g2_obj_render"][2], rtol=1e-14, atol=0)
+    big = np.random.RandomState(0).uniform(-0.4, 0.4, (100000, 3))
+    for fn in (g.get_render_location, cnative.project_fma):
+        r = fn(big, cam)
+        sub = z["g2_big_sub_index"]
+        assert np.array_equal(r[:2, sub], z["g2_big_sub_render"][:2])
+        assert np.allclose(r[2, sub], z["g2_big_sub_render"][2], rtol=1e-14, atol=0)
+        digest = hashlib.sha256(np.ascontiguousarray(r[:2]).tobytes()).digest()
+        assert np.array_equal(np.frombuffer(digest, dtype=np.uint8), z["g2_big_uv_sha256"])
+
+
+@pytest.mark.parametrize("tag", ["near", "std", "tilt"])
+@pytest.mark.parametrize("dname", ["surface", "const", "plane"])
+def test_depth_visibility(golden_geometry, tag, dname):
+    z = golden_geometry
+    r = z[f"g3_{tag}_render"]
+    d = (np.full((540, 960), 3.0, np.float32) if dname == "const" else z[f"g3_{tag}_depth_{dname}"])
+    ta, same = g.depth_visibility_array_a(r.copy(), d)
+    assert np.array_equal(ta, z[f"g3_{tag}_{dname}_truth_a"])
+    tb, pruned = g.depth_visibility_array_b(r.copy(), d)
+    assert np.array_equal(tb, z[f"g3_{tag}_{dname}_truth_b"])
+    assert np.array_equal(pruned, z[f"g3_{tag}_{dname}_pruned_b"])
+    # the fixture must exercise both outcomes and the frame border
+    if dname == "surface":
+        assert 0 < ta.sum() < ta.size and 0 < tb.sum() < tb.size
+
+
+def test_depth_visibility_literal_matches_vectorised(golden_geometry):
+    z = golden_geometry
+    r = z["g3_near_render"][:, :800]
+    d = z["g3_near_depth_surface"]
+    assert np.array_equal(g.depth_visibility_literal(r, d, "A"), g.depth_visibility_array_a(r, d)[0])
+    assert np.array_equal(g.depth_visibility_literal(r, d, "B"), g.depth_visibility_array_b(r, d)[0])
+
+
+def test_depth_visibility_edges(golden_geometry):
+    z = golden_geometry
+    r, d = z["g3_edge_render"], z["g3_edge_depth"]
+    assert np.array_equal(g.depth_visibility_array_a(r.copy(), d)[0], z["g3_edge_truth_a"])
+    assert np.array_equal(g.depth_visibility_array_b(r.copy(), d)[0], z["g3_edge_truth_b"])
+    # x = 950 and y = 0 / 540 are outside the gate; x = 949, y = 539 inside
+    assert not z["g3_edge_truth_a"][7] and z["g3_edge_truth_a"][6]
+
+
+@pytest.mark.parametrize("tag", ["wide", "tall", "square", "odd"])
+def test_crop_remap(golden_geometry, tag):
+    z = golden_geometry
+    arr = z["g3_std_render"].copy()
+    t, same = g.crop_visibility_array(arr, z[f"g4_{tag}_crop"].tolist())
+    assert same is arr                      # in-place contract
+    assert np.array_equal(t, z[f"g4_{tag}_truth"])
+    assert np.array_equal(arr, z[f"g4_{tag}_render"])
+
+
+def test_crop_noresize(golden_geometry):
+    z = golden_geometry
+    arr = z["g3_std_render"].copy()
+    t, _ = g.crop_visibility_array(arr, [100, 400, 300, 700], resize=False)
+    assert np.array_equal(t, z["g4_noresize_truth"]) and np.array_equal(arr, z["g4_noresize_render"])
+
+
+@pytest.mark.parametrize("tag", ["cloud", "mesh", "edge"])
+def test_make_disparity(golden_disparity, tag):
+    z = golden_disparity
+    args = (z[f"{tag}_pts"], z[f"{tag}_params"].tolist(), z[f"{tag}_depth"], z[f"{tag}_crop"].tolist())
+    want = z[f"{tag}_flow"]
+    assert np.array_equal(disparity.make_disparity_core(*args, literal=True), want)
+    assert np.array_equal(disparity.make_disparity_core(*args), want)
+    assert np.count_nonzero(want) > 1000
+
+
+def test_splat_python_slice_semantics():
+    # negative starts wrap; a start that wraps past the stop gives an empty slice
+    uv = np.array([[0, 1, 2, 223, 230, -5, 100], [50, 50, 50, 223, 10, 60, -3]], dtype=np.float64)
+    delta = np.arange(14, dtype=np.float64).reshape(2, 7) + 1
+    a = disparity.splat_flow_literal(uv, delta)
+    b = disparity.splat_flow(uv, delta)
+    assert np.array_equal(a, b)
+    assert a[50, 0, 0] == 3.0 and a[48:52, 0:4, 0].tolist() == [[3.0] * 4] * 4   # only u=2 writes
+    assert a[221:224, 221:224, 0].min() == 4.0
+    assert a[58:62, 217:221, 0].min() == 6.0                                     # u=-5 wraps
+    assert g.py_slice_bounds(1, 2, 224) == (223, 223) and g.py_slice_bounds(-5, 2, 224) == (217, 221)
+
+
+@pytest.mark.parametrize("name", ANCHORS)
+def test_get_render_array_variant_b(golden_disparity, golden_geometry, name):
+    z = golden_disparity
+    fd = {"azimuth": 120.0, "elevation": 10.0, "tilt": 0.0, "rho": 2.2, "crop_params": [60, 480, 250, 720]}
+    truth, crop_pts = g.get_render_array(fd, golden_geometry[f"g2_anchor_{name}"], z[f"rb_{name}_depth"])
+    assert np.array_equal(truth, z[f"rb_{name}_truth"])
+    assert np.array_equal(crop_pts, z[f"rb_{name}_crop_pts"])
+
+
+def test_pt_depth_map(golden_disparity):
+    z = golden_disparity
+    assert np.array_equal(g.get_pt_depth_map(z["ptdepth_render"]), z["ptdepth_map"])
+
+
+@pytest.mark.parametrize("tag", ["b1k1", "b2k10", "b3k14"])
+def test_correlation_eccv(golden_correlation, tag):
+    z = golden_correlation
+    f1 = z[f"{tag}_f1"].astype(np.float32)
+    f2 = z[f"{tag}_f2"].astype(np.float32)
+    got = correlation.correlation_map_eccv(f1, f2, z[f"{tag}_knn"])
+    want = z[f"{tag}_out"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-8)
+
+
+def test_bilinear_resize(golden_correlation):
+    z = golden_correlation
+    got = correlation.bilinear_align_corners(z["resize_in"], 28, 28)
+    # last-bit differences only (torch contracts multiply-adds in its own order)
+    assert np.allclose(got, z["resize_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_acmm_shares_contraction_with_eccv(golden_correlation):
+    z = golden_correlation
+    f1 = z["b2k10_f1"].astype(np.float32)
+    f2 = z["b2k10_f2"].astype(np.float32)
+    mask = np.ones((2, 1, 56, 56), np.float32)
+    acmm = correlation.correlation_map_acmm(f1, f2, mask)
+    # rows p of acmm(f1, f2) un-normalised == eccv(real=f2, template=f1) at template cell p
+    knn = np.array([[3, 5], [27, 0], [0, 27]])
+    f1r = correlation.bilinear_align_corners(f1, 28, 28)
+    f2r = correlation.bilinear_align_corners(f2, 28, 28)
+    raw = np.maximum(np.einsum("bcp,bcyx->bpyx", f1r.reshape(2, -1, 784), f2r), 0)
+    norm = np.sqrt((raw ** 2).sum(1, keepdims=True))
+    for x, y in knn:
+        p = y * 28 + x
+        assert np.allclose(acmm[:, p], (raw / norm)[:, p], rtol=1e-5, atol=1e-7)
+    assert np.allclose(np.sqrt((acmm ** 2).sum(1)), 1.0, atol=1e-4)
+
+
+def test_l2norm():
+    x = np.random.RandomState(3).randn(2, 16, 5, 5).astype(np.float32)
+    y = correlation.l2norm(x)
+    assert np.allclose((y ** 2).sum(1), 1.0, atol=1e-6)
+
+
+def test_nn_exact_c_equals_numpy():
+    rs = np.random.RandomState(5)
+    q = rs.randn(24, 150).astype(np.float32)
+    r = rs.randn(24, 333).astype(np.float32)
+    r[:, 40] = r[:, 7]                       # exact duplicate -> tie, lowest index must win
+    q[:, 3] = r[:, 7]
+    for k in (1, 5):
+        i_np, d_np = nn.nn_exact_numpy(q, r, k)
+        i_c, d_c = cnative.nn_exact(q, r, k)
+        assert np.array_equal(i_np, i_c) and np.array_equal(d_np, d_c)
+    i1, d1 = cnative.nn_exact(q, r, 2)
+    assert i1[0, 3] == 8 and i1[1, 3] == 41 and d1[0, 3] == 0.0   # 1-based
+    i0, _ = cnative.nn_exact(q, r, 1, index_base=0)
+    assert np.array_equal(i0 + 1, i1[:1])
+
+
+def test_round_bf16():
+    x = np.array([1.0, 1.00390625, 1.005859375, -3.1415927, 1e-40, np.inf], np.float32)
+    y = cnative.round_bf16(x)
+    assert y[0] == 1.0 and y[1] == 1.0 and y[2] == 1.0078125 and np.isinf(y[5])
+    assert (y.view(np.uint32) & 0xFFFF == 0).all()
+
+
+def test_zbuffer_oracle():
+    pr = np.array([[10, 10, 10, 500, -1, 959], [20, 20, 20, 100, 5, 539], [2.0, 1.5, 1.5, 3.0, 1.0, 4.0]])
+    key, win, depth = zbuffer.zbuffer(pr, 540, 960)
+    assert win[20, 10] == 1 and depth[20, 10] == np.float32(1.5)   # lowest index among equal depth
+    assert win[100, 500] == 3 and win[539, 959] == 5 and win[0, 0] == -1
+    vis = zbuffer.zbuffer_visibility(pr, depth)
+    assert vis.tolist() == [False, True, True, True, False, True]
+
+
+def test_filename_codec_and_keypoints(golden_geometry):
+    name = "04256520_1fd45c57ab27cb6cea65c47b660136e7_a90@179_e0@236_t0@000_d3@000_199_343_385_575_.jpg"
+    d = kp.get_params_from_syn_file("x/y/" + name)
+    assert d["azimuth"] == 90.179 and d["tilt"] == -0.0 and d["crop_params"] == [199, 343, 385, 575]
+    assert kp.img_to_depth_file(name) == name[:-len("_199_343_385_575_.jpg")] + ".png1.exr"
+    assert kp.render_file_name(d) == name.replace("a90@179", "a90@179").replace("_t0@000", "_t-0@000") \
+        or kp.render_file_name(d) == name
+    chair = golden_geometry["g2_anchor_chair"]
+    dense = kp.dense_skeleton_3d(chair, "chair")
+    assert dense.shape == (3, 130)
+    assert np.array_equal(dense[:, 0], chair[4]) and np.array_equal(dense[:, 9], chair[0])
+    grid = kp.knn_inds_to_grid(np.array([[-4.0, 10.0], [223.9, 300.0], [8.0, 15.99]]))
+    assert grid.tolist() == [[0, 1], [27, 27], [1, 1]]
+    xy = kp.ind2coord(np.array([[[1, 57, 3136]]]), 56)
+    assert xy[0, 0].tolist() == [[0, 0], [0, 4], [220, 220]]
+    params = np.array([[0, 10, 0], [350, 0, 0], [120, 10, 0], [10, 80, 0]], dtype=np.float64)
+    assert kp.nearest_view([355, 0, 0], params) == 1 and kp.nearest_view([2, 9, 0], params) == 0
