@@ -1,0 +1,177 @@
+/*
+ * ispa_abi.h -- C ABI of libispa_hip.so, the MI355X (gfx950) implementation of the dense
+ * correspondence / disparity path of val-iisc/pose_estimation.
+ *
+ * The reference is pure Python; it has no FFI layer.  Each entry point below replaces the
+ * Python function (or external Caffe layer) cited beside it, and is what a ctypes stub in the
+ * reference would bind (INTEGRATION.md shows those stubs).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is called host_*;
+ *   - the caller allocates and owns every buffer, including workspaces; the library keeps no
+ *     reference to them after the call returns and never allocates or frees device memory;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *     and is asynchronous with respect to the host;
+ *   - return value 0 = ok, negative = ispa_status; ispa_last_error() returns a thread-local
+ *     message for the last failing call on the calling thread;
+ *   - arrays are C-ordered; "pt_render" always means the reference's (3, N) float64 layout with
+ *     rows [u, v, z] (pt2render.py:6-13), batched as (n_pose, 3, N).
+ */
+#ifndef ISPA_ABI_H
+#define ISPA_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISPA_ABI_VERSION 1
+
+typedef enum ispa_status {
+    ISPA_OK = 0,
+    ISPA_EINVAL = -1,       /* bad argument (shape, null pointer, unsupported value) */
+    ISPA_EHIP = -2,         /* a HIP runtime call or kernel launch failed             */
+    ISPA_EWORKSPACE = -3,   /* workspace too small                                    */
+    ISPA_EUNSUPPORTED = -4  /* valid request this build has no kernel for             */
+} ispa_status;
+
+enum { ISPA_VIS_A = 0, ISPA_VIS_B = 1 };          /* depth-visibility variants         */
+enum { ISPA_F32 = 0, ISPA_BF16 = 1 };             /* feature dtypes for ispa_nn_topk   */
+
+int ispa_abi_version(void);
+const char *ispa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry: projection, visibility, crop remap
+ * ---------------------------------------------------------------------------------------- */
+
+/* get_render_location(pt_array, camera_matrix)
+ *   data_creator/render_wt_pt_proj/pt2render.py:6-13 (same code at
+ *   classifier_code/train_test_scripts/utils/pt2render.py:6-13), batched over camera matrices.
+ * pts (n,3) f64; cams (n_pose,3,4) f64; out (n_pose,3,n) f64 = [rint(x/z), rint(y/z), z].
+ * x,y,z are the k-sequential fma chain fma(P[r][3],1,fma(P[r][2],pz,fma(P[r][1],py,P[r][0]*px))). */
+int ispa_project(const double *pts, int64_t n, const double *cams, int n_pose, double *out,
+                 void *stream);
+
+/* depth_visibility_array(pt_render, depth_map, error_relaxation)
+ *   variant ISPA_VIS_A: data_creator/render_wt_pt_proj/pt2render.py:43-55
+ *       truth = gate && |z - depth[y][x]| <= relax
+ *   variant ISPA_VIS_B: classifier_code/train_test_scripts/utils/pt2render.py:43-53
+ *       truth = gate && z <= min_{3x3, clipped}(depth + (float)relax)   (sum and min in float)
+ *   gate: y = (int)v, x = (int)u, 0 < y < ylim, 0 < x < xlim   (reference: 540, 950).
+ * depth is (H,W) f32 shared by all poses (depth_per_pose = 0) or (n_pose,H,W).
+ * truth (n_pose, n) bytes 0/1.  pt_render is not modified (the pruned copy variant B returns
+ * is a host-side selection by truth). */
+int ispa_depth_visibility(const double *pt_render, int64_t n, int n_pose, const float *depth,
+                          int depth_per_pose, int H, int W, int ylim, int xlim, double relax,
+                          int variant, uint8_t *truth, void *stream);
+
+/* crop_visibility_array(pt_render, crop_params, resize)
+ *   data_creator/render_wt_pt_proj/pt2render.py:18-38.  IN PLACE on rows 0,1 of pt_render.
+ * crop (n_pose,4) int32 [top,bottom,left,right], or one row shared (crop_per_pose = 0). */
+int ispa_crop_remap(double *pt_render, int64_t n, int n_pose, const int32_t *crop,
+                    int crop_per_pose, int resize, uint8_t *truth, void *stream);
+
+/* get_3d_to_2d + prune_pts            data_creator/render_wt_pt_proj/run_proj.py:24-46
+ * get_render_array                    classifier_code/train_test_scripts/utils/io_utils.py:97-117
+ * One pass: project, depth-visibility (variant), optional crop test + remap.
+ * crop may be NULL (no crop: coordinates stay in render pixels, truth = depth truth).
+ * out (n_pose,3,n) f64; truth (n_pose,n) = crop_truth * depth_truth;
+ * truth_depth / truth_crop (n_pose,n) optional (NULL to skip). */
+int ispa_project_prune(const double *pts, int64_t n, const double *cams, int n_pose,
+                       const float *depth, int depth_per_pose, int H, int W, int ylim, int xlim,
+                       double relax, int variant, const int32_t *crop, int crop_per_pose,
+                       double *out, uint8_t *truth, uint8_t *truth_depth, uint8_t *truth_crop,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Splat writers
+ * ---------------------------------------------------------------------------------------- */
+
+/* Flow splat of make_disparity      data_creator/make_disparity_syn.py:55-68
+ * uv1, uv2 (n_map,3,n) f64 crop coordinates of pose 1 / pose 2; truth (n_map,n) = truth_1.
+ * For every kept point in index order: flow[v-s:v+s, u-s:u+s, :] = (uv2-uv1)[:2] with Python
+ * slice semantics, i.e. per pixel the kept point with the HIGHEST index wins.
+ * owner_ws (n_map, side*side) int32 scratch; flow (n_map, side, side, 2) f64. */
+int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
+                    int n_map, int spread, int side, int32_t *owner_ws, double *flow,
+                    void *stream);
+
+/* get_pt_depth_map(render_array, size, radius)
+ *   classifier_code/train_test_scripts/utils/io_utils.py:119-124: z splat, last writer wins.
+ * owner_ws (H*W) int32 scratch; depth_out (H,W) f64. */
+int ispa_point_depth_splat(const double *pt_render, int64_t n, int H, int W, int radius,
+                           int32_t *owner_ws, double *depth_out, void *stream);
+
+/* Z-buffer of the projected points (no counterpart in the reference, which reads a rendered
+ * depth image): per pixel the minimum of (bits(float(z)) << 32 | index) over the points whose
+ * (2*radius+1)^2 block covers it.  packed (n_pose,H,W) u64 scratch/out; winner (n_pose,H,W)
+ * int32 (-1 empty) and depth (n_pose,H,W) f32 (+inf empty) are optional outputs. */
+int ispa_zbuffer(const double *pt_render, int64_t n, int n_pose, int H, int W, int radius,
+                 uint64_t *packed, int32_t *winner, float *depth, void *stream);
+
+/* visible = takes part && (double)z - (double)depth[y][x] <= relax. */
+int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, const float *depth,
+                            int H, int W, double relax, uint8_t *truth, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense nearest-neighbour correspondence
+ * ---------------------------------------------------------------------------------------- */
+
+/* `KNN` layer of the Caffe-UCN fork as used at ucn_code/nets/train.prototxt:2116-2141
+ * (external to the reference; consumer hard_negative_processing_layer.py:175-192).
+ * q (B,C,nq), r (B,C,nr): NCHW feature maps with the spatial axes flattened; dtype ISPA_F32
+ * (float) or ISPA_BF16 (bfloat16 bits).  For every query column the k references with the
+ * smallest squared L2 distance, ordered by (distance, index); the index order is EXACT with
+ * respect to float64 arithmetic on the given inputs (MFMA filter pass + float64 re-scoring of
+ * every query whose filter margin is inside the rounding bound).
+ * idx (B,k,nq) int32 = flat reference index + index_base (the reference's layer is 1-based);
+ * dist (B,k,nq) f32 squared distances; stats (optional, 4 int32): [0] = number of queries that
+ * took the float64 path. */
+size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);
+int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
+                 int k, int index_base, float *dist, int32_t *idx, void *workspace,
+                 size_t workspace_bytes, int32_t *stats, void *stream);
+
+/* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
+ * next n ispa_nn_topk calls of this process brackets its filter kernel -- the launch that does
+ * the MFMA contraction -- with HIP events on the call's stream.  ispa_timing_collect waits for
+ * them, writes the elapsed milliseconds of the recorded calls to a HOST array and re-arms the
+ * slots.  ispa_timing_enable(0) turns it off and releases the events.  Not thread-safe. */
+int ispa_timing_enable(int max_records);
+int ispa_timing_collect(float *host_ms, int capacity, int *host_count);
+
+/* L2NormLayer.forward                 ucn_code/lib/layers/l2norm_layer.py:18-29
+ * x, out (B,C,hw) f32: out = x / sqrt(sum_c x^2), no epsilon. */
+int ispa_l2norm(const float *x, int B, int C, int64_t hw, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Correlation maps
+ * ---------------------------------------------------------------------------------------- */
+
+/* torch.nn.UpsamplingBilinear2d(size) (align_corners=True) as called at
+ * eccv_net.py:184-185 and net_final_old.py:33-34.  in (B,C,H,W) -> out (B,C,oh,ow) f32. */
+int ispa_resize_bilinear(const float *in, int B, int C, int H, int W, int oh, int ow, float *out,
+                         void *stream);
+
+/* eccv_net.CorrelationMapLayer.forward(feature1, feature2, knn_inds)
+ *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:181-231
+ * f1 (real), f2 (template): (B,C,H,W) f32; knn (K,2) int64 [x,y] on the grid x grid lattice.
+ * out (B,K,grid,grid) f32 = relu(corr) / sum_yx exp(relu(corr)) * 10.
+ * workspace: 2*B*C*grid*grid floats. */
+int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
+                       int W, int K, int grid, float *out, float *workspace, void *stream);
+
+/* acmm_net CorrelationMapLayer.forward, correlation part
+ *   classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
+ * mask (B,1,H,W) f32 (max-pooled 2x2 ceil inside).  out (B, grid*grid, grid, grid) f32.
+ * workspace: 2*B*C*grid*grid floats. */
+int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
+                       int W, int grid, float *out, float *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISPA_ABI_H */

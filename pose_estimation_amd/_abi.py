@@ -1,0 +1,71 @@
+"""ctypes binding of libispa_hip.so (declarations mirror include/ispa_abi.h).
+
+There is no CPU fallback: if the shared library is missing or does not export a symbol,
+importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libispa_hip.so")
+
+ISPA_ABI_VERSION = 1
+VIS_A, VIS_B = 0, 1
+F32, BF16 = 0, 1
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_d = ctypes.c_double
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); one entry per declaration in include/ispa_abi.h
+SIGNATURES = {
+    "ispa_abi_version": (_i, []),
+    "ispa_last_error": (ctypes.c_char_p, []),
+    "ispa_project": (_i, [_p, _i64, _p, _i, _p, _p]),
+    "ispa_depth_visibility": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _i, _d, _i, _p, _p]),
+    "ispa_crop_remap": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p]),
+    "ispa_project_prune": (_i, [_p, _i64, _p, _i, _p, _i, _i, _i, _i, _i, _d, _i, _p, _i, _p, _p, _p, _p, _p]),
+    "ispa_flow_splat": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p]),
+    "ispa_point_depth_splat": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p]),
+    "ispa_zbuffer": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "ispa_zbuffer_visibility": (_i, [_p, _i64, _i, _p, _i, _i, _d, _p, _p]),
+    "ispa_nn_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i]),
+    "ispa_nn_topk": (_i, [_p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p, _p, _p, _sz, _p, _p]),
+    "ispa_timing_enable": (_i, [_i]),
+    "ispa_timing_collect": (_i, [_p, _i, _p]),
+    "ispa_l2norm": (_i, [_p, _i, _i, _i64, _p, _p]),
+    "ispa_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "ispa_corr_map_eccv": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "ispa_corr_map_acmm": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+}
+
+
+class IspaError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C pose_estimation_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "pose_estimation_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.ispa_abi_version()
+    if got != ISPA_ABI_VERSION:
+        raise ImportError(f"libispa_hip.so has ABI version {got}, binding expects {ISPA_ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise IspaError(f"ispa error {rc}: {lib.ispa_last_error().decode(errors='replace')}")

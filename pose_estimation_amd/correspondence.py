@@ -1,0 +1,162 @@
+"""Dense nearest-neighbour correspondence and keypoint correlation maps.
+
+  dense_nn                 the `KNN` layer contract of ucn_code/nets/train.prototxt:2116-2141
+  l2norm                   ucn_code/lib/layers/l2norm_layer.py:18-29
+  ind2coord                ucn_code/lib/layers/hard_negative_processing_layer.py:44-58,188-189
+  CorrelationMapLayer      classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:161-231
+  correlation_map_acmm     classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
+  get_pt, knn_inds_to_grid classifier_code/train_test_scripts/utils/proxy_renderer.py:50-58 and
+                           multi_view_train.py:164,177 + eccv_net.py:282
+"""
+import numpy as np
+import torch
+
+from . import _abi, _device as dv, io_utils
+
+_workspaces = {}
+
+
+def _workspace(nbytes):
+    """Per-device scratch owned by this module (grown on demand, reused across calls)."""
+    key = torch.cuda.current_device()
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dv.device())
+        _workspaces[key] = ws
+    return ws
+
+
+def dense_nn(query, ref, k=1, index_base=1, return_stats=False):
+    """k nearest reference cells (squared L2) for every query column.
+
+    query (B,C,Hq,Wq) or (B,C,n); ref (B,C,H,W) or (B,C,nr); float32, or bfloat16 torch tensors.
+    Returns dist (B,k,n) float32 and ind (B,k,n) int32 with ind = y*W + x + index_base (the
+    reference's layer is 1-based), neighbours ordered by (distance, index).  The index order is
+    exact with respect to float64 arithmetic on the given inputs."""
+    as_tensor = dv.is_tensor(query)
+    bf16 = as_tensor and query.dtype == torch.bfloat16
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    q = dv.to_dev(query, tdt)
+    r = dv.to_dev(ref, tdt)
+    if q.dim() < 3 or r.dim() < 3 or q.shape[0] != r.shape[0] or q.shape[1] != r.shape[1]:
+        raise ValueError(f"query {tuple(q.shape)} and ref {tuple(r.shape)} must share batch and channels")
+    b, c = q.shape[:2]
+    q = q.reshape(b, c, -1)
+    r = r.reshape(b, c, -1)
+    nq, nr = q.shape[2], r.shape[2]
+    if not 1 <= k <= 8:
+        raise ValueError("k must be in [1, 8]")
+    dist = dv.empty((b, k, nq), torch.float32)
+    ind = dv.empty((b, k, nq), torch.int32)
+    stats = torch.zeros(4, dtype=torch.int32, device=dv.device())
+    need = _abi.lib.ispa_nn_workspace_bytes(b, c, nq, nr, k)
+    ws = _workspace(max(need, 256))
+    _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), _abi.BF16 if bf16 else _abi.F32, b, c, nq, nr, k,
+                                     int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
+                                     dv.ptr(stats), dv.stream_ptr()))
+    out = (dv.back(dist, as_tensor), dv.back(ind, as_tensor))
+    if return_stats:
+        out += ({"exact_path_queries": int(stats[0].item())},)
+    return out
+
+
+def l2norm(x):
+    """x (B,C,...) float32 -> x / sqrt(sum_c x^2); no epsilon, like the reference layer."""
+    as_tensor = dv.is_tensor(x)
+    t = dv.to_dev(x, torch.float32)
+    b, c = t.shape[:2]
+    flat = t.reshape(b, c, -1)
+    out = torch.empty_like(flat)
+    _abi.check(_abi.lib.ispa_l2norm(dv.ptr(flat), b, c, flat.shape[2], dv.ptr(out), dv.stream_ptr()))
+    return dv.back(out.reshape(t.shape), as_tensor)
+
+
+def ind2coord(ind, width, downsampling_factor=4, index_base=1):
+    """Flat KNN index -> (x, y) image coordinates: x = i % W, y = floor(i / W), times the
+    feature stride (hard_negative_processing_layer.py:44-58 after the `- 1` of line 188)."""
+    i = np.asarray(ind) - index_base
+    return np.stack([i % width, np.floor(i / width)], axis=-1) * downsampling_factor
+
+
+def resize_bilinear(x, size):
+    as_tensor = dv.is_tensor(x)
+    t = dv.to_dev(x, torch.float32)
+    b, c, h, w = t.shape
+    out = dv.empty((b, c, size[0], size[1]), torch.float32)
+    _abi.check(_abi.lib.ispa_resize_bilinear(dv.ptr(t), b, c, h, w, size[0], size[1], dv.ptr(out),
+                                             dv.stream_ptr()))
+    return dv.back(out, as_tensor)
+
+
+class CorrelationMapLayer:
+    """eccv_net.CorrelationMapLayer: forward(feature1, feature2, knn_inds) -> (B,K,28,28).
+
+    feature1 = real-image features, feature2 = template features, (B,C,H,W) float32;
+    knn_inds (K,2) integer [x, y] template cells on the 28 x 28 grid."""
+
+    def __init__(self, grid=28):
+        self.grid = grid
+
+    def forward(self, feature1, feature2, knn_inds):
+        as_tensor = dv.is_tensor(feature1)
+        f1 = dv.to_dev(feature1, torch.float32)
+        f2 = dv.to_dev(feature2, torch.float32)
+        if f1.shape != f2.shape or f1.dim() != 4:
+            raise ValueError("feature maps must be two (B,C,H,W) arrays of the same shape")
+        knn = dv.to_dev(knn_inds, torch.int64).reshape(-1, 2)
+        if knn.numel() and (int(knn.min()) < 0 or int(knn.max()) >= self.grid):
+            raise IndexError(f"knn_inds outside the {self.grid} x {self.grid} grid")
+        b, c, h, w = f1.shape
+        k = knn.shape[0]
+        out = dv.empty((b, k, self.grid, self.grid), torch.float32)
+        ws = _workspace(2 * b * c * self.grid * self.grid * 4)
+        _abi.check(_abi.lib.ispa_corr_map_eccv(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, c, h, w, k, self.grid,
+                                               dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
+        return dv.back(out, as_tensor)
+
+    __call__ = forward
+
+
+def correlation_map_acmm(feature1, feature2, mask, grid=28):
+    """net_final_old.py:33-61 -> (B, grid*grid, grid, grid) float32; mask (B,1,H,W)."""
+    as_tensor = dv.is_tensor(feature1)
+    f1 = dv.to_dev(feature1, torch.float32)
+    f2 = dv.to_dev(feature2, torch.float32)
+    m = dv.to_dev(mask, torch.float32)
+    b, c, h, w = f1.shape
+    if m.shape != (b, 1, h, w):
+        raise ValueError(f"mask must be ({b},1,{h},{w})")
+    out = dv.empty((b, grid * grid, grid, grid), torch.float32)
+    ws = _workspace(2 * b * c * grid * grid * 4)
+    _abi.check(_abi.lib.ispa_corr_map_acmm(dv.ptr(f1), dv.ptr(f2), dv.ptr(m), b, c, h, w, grid, dv.ptr(out),
+                                           dv.ptr(ws), dv.stream_ptr()))
+    return dv.back(out, as_tensor)
+
+
+def get_pt(anchors, file_name, depth):
+    """proxy_renderer.get_pt: anchors (K,3) -> (1,K,3) = [u224, v224, visible] for the render
+    named file_name, through the variant-B pruning.  depth: directory or (H,W) array."""
+    anchors = np.asarray(anchors, dtype=np.float64)
+    truth, crop_pts = io_utils.get_render_array(io_utils.get_params_from_file(file_name), anchors, depth)
+    out = np.zeros((1, anchors.shape[0], 3))
+    out[0, :, :2] = crop_pts[:2, :].T
+    out[0, :, 2] = truth
+    return out
+
+
+def knn_inds_to_grid(knn_xy, grid=28, image=224):
+    """clip to [0, image-1], divide by image/grid, truncate -- the path from get_pt's pixel
+    coordinates to CorrelationMapLayer's integer cells."""
+    return (np.clip(np.asarray(knn_xy, dtype=np.float64), 0, image - 1) / (float(image) / grid)).astype(np.int64)
+
+
+def nearest_view(view_params, param_np):
+    """proxy_renderer.proxy_render's lookup (lines 101-106): index of the stored pose closest to
+    view_params, angle differences wrapped, elevation and tilt weighted 1/8."""
+    d = np.array(param_np, dtype=np.float64) - np.asarray(view_params, dtype=np.float64)
+    for col, half in ((0, 180.0), (1, 90.0), (2, 180.0)):
+        c = d[:, col].copy()
+        d[c >= half, col] -= 2 * half
+        d[c < -half, col] += 2 * half
+    d[:, 1:] /= 8.0
+    return int(np.argmin(np.linalg.norm(d, axis=1)))

@@ -1,0 +1,48 @@
+// Shared host-side helpers for libispa_hip.so (error reporting, argument checks, launch sizing).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "ispa_abi.h"
+
+namespace ispa {
+
+char *last_error_buffer();  // thread-local, 512 bytes
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ISPA_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return ISPA_OK;
+}
+
+#define ISPA_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return ::ispa::fail(ISPA_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define ISPA_HIP(call)                                                                   \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return ::ispa::fail(ISPA_EHIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+inline unsigned blocks_for(int64_t work, int threads, int64_t cap = 1 << 20) {
+    int64_t b = (work + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace ispa

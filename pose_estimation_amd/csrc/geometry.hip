@@ -1,0 +1,262 @@
+// Projection, depth visibility and crop remap kernels (float64, bandwidth-bound).
+//
+// Arithmetic follows the reference's numpy code operation by operation so that rounded pixel
+// coordinates and visibility flags are bit-exact:
+//   pt2render.py:6-13   P @ [p;1] as a k-sequential fma chain (what dgemm does), divide, rint
+//   pt2render.py:18-38  crop: subtract, multiply, add pad, rint -- separate roundings (this
+//                       file is compiled with -ffp-contract=off; every fused op is explicit)
+//   pt2render.py:43-55  (A) and classifier_code/.../utils/pt2render.py:43-53 (B) visibility
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr double kCropSide = 224.0;
+
+struct CropXform {
+    double top, bottom, left, right;  // crop box as doubles (exact: they are int32)
+    double ratio, pad_x, pad_y;
+};
+
+__device__ __forceinline__ CropXform make_crop(const int32_t *c) {
+    CropXform x;
+    x.top = (double)c[0];
+    x.bottom = (double)c[1];
+    x.left = (double)c[2];
+    x.right = (double)c[3];
+    const int y_len = c[1] - c[0];
+    const int x_len = c[3] - c[2];
+    x.pad_x = 0.0;
+    x.pad_y = 0.0;
+    if (y_len >= x_len) {
+        x.ratio = kCropSide / (double)y_len;
+        x.pad_x = (kCropSide - (double)x_len * x.ratio) / 2.0;
+    } else {
+        x.ratio = kCropSide / (double)x_len;
+        x.pad_y = (kCropSide - (double)y_len * x.ratio) / 2.0;
+    }
+    return x;
+}
+
+// Strict crop test on the un-cropped coordinates, then the in-place remap.
+__device__ __forceinline__ bool crop_apply(const CropXform &c, int y_ge_x, int resize, double &u,
+                                           double &v) {
+    const bool inside = (v > c.top) && (v < c.bottom) && (u > c.left) && (u < c.right);
+    u = u - c.left;
+    v = v - c.top;
+    if (resize) {
+        u = u * c.ratio;
+        v = v * c.ratio;
+        if (y_ge_x)
+            u = u + c.pad_x;
+        else
+            v = v + c.pad_y;
+        u = rint(u);
+        v = rint(v);
+    }
+    return inside;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ bool depth_test(double u, double v, double z,
+                                           const float *__restrict__ depth, int H, int W, int ylim,
+                                           int xlim, double relax) {
+    // int() truncation of the already rounded coordinate; NaN/inf fail every comparison.
+    const double yt = trunc(v), xt = trunc(u);
+    if (!(yt > 0.0 && yt < (double)ylim && xt > 0.0 && xt < (double)xlim)) return false;
+    const int y = (int)yt, x = (int)xt;
+    if (VARIANT == ISPA_VIS_A) {
+        const double d = (double)depth[(int64_t)y * W + x];
+        return fabs(z - d) <= relax;
+    } else {
+        const float r32 = (float)relax;
+        float best = __builtin_inff();
+        const int y1 = min(y + 2, H), x1 = min(x + 2, W);
+        for (int yy = y - 1; yy < y1; ++yy)
+            for (int xx = x - 1; xx < x1; ++xx) best = fminf(best, depth[(int64_t)yy * W + xx] + r32);
+        return z <= (double)best;
+    }
+}
+
+__device__ __forceinline__ void project_point(const double *__restrict__ P, double px, double py,
+                                              double pz, double &u, double &v, double &z) {
+    double a[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double acc = P[4 * r + 0] * px;
+        acc = fma(P[4 * r + 1], py, acc);
+        acc = fma(P[4 * r + 2], pz, acc);
+        acc = fma(P[4 * r + 3], 1.0, acc);
+        a[r] = acc;
+    }
+    z = a[2];
+    u = rint(a[0] / a[2]);
+    v = rint(a[1] / a[2]);
+}
+
+__global__ __launch_bounds__(kThreads) void project_kernel(const double *__restrict__ pts, int64_t n,
+                                                           const double *__restrict__ cams,
+                                                           int n_pose, int poses_per_block,
+                                                           double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const int p0 = blockIdx.y * poses_per_block;
+    const int p1 = min(p0 + poses_per_block, n_pose);
+    for (int p = p0; p < p1; ++p) {
+        double u, v, z;
+        project_point(cams + 12 * (int64_t)p, px, py, pz, u, v, z);
+        double *o = out + (int64_t)p * 3 * n;
+        o[i] = u;
+        o[n + i] = v;
+        o[2 * n + i] = z;
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kThreads) void depth_visibility_kernel(
+    const double *__restrict__ pt_render, int64_t n, int n_pose, const float *__restrict__ depth,
+    int depth_per_pose, int H, int W, int ylim, int xlim, double relax, uint8_t *__restrict__ truth) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= n) return;
+    const double *r = pt_render + (int64_t)p * 3 * n;
+    const float *d = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
+    truth[(int64_t)p * n + i] = depth_test<VARIANT>(r[i], r[n + i], r[2 * n + i], d, H, W, ylim, xlim, relax);
+}
+
+__global__ __launch_bounds__(kThreads) void crop_remap_kernel(double *__restrict__ pt_render, int64_t n,
+                                                              const int32_t *__restrict__ crop,
+                                                              int crop_per_pose, int resize,
+                                                              uint8_t *__restrict__ truth) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= n) return;
+    const int32_t *c = crop + (crop_per_pose ? 4 * (int64_t)p : 0);
+    const CropXform cx = make_crop(c);
+    double *r = pt_render + (int64_t)p * 3 * n;
+    double u = r[i], v = r[n + i];
+    const bool inside = crop_apply(cx, (c[1] - c[0]) >= (c[3] - c[2]), resize, u, v);
+    r[i] = u;
+    r[n + i] = v;
+    if (truth) truth[(int64_t)p * n + i] = inside;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kThreads) void project_prune_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams, int n_pose,
+    int poses_per_block, const float *__restrict__ depth, int depth_per_pose, int H, int W, int ylim,
+    int xlim, double relax, const int32_t *__restrict__ crop, int crop_per_pose,
+    double *__restrict__ out, uint8_t *__restrict__ truth, uint8_t *__restrict__ truth_depth,
+    uint8_t *__restrict__ truth_crop) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const int p0 = blockIdx.y * poses_per_block;
+    const int p1 = min(p0 + poses_per_block, n_pose);
+    for (int p = p0; p < p1; ++p) {
+        double u, v, z;
+        project_point(cams + 12 * (int64_t)p, px, py, pz, u, v, z);
+        const float *d = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
+        const bool vis = depth_test<VARIANT>(u, v, z, d, H, W, ylim, xlim, relax);
+        bool inside = true;
+        if (crop) {
+            const int32_t *c = crop + (crop_per_pose ? 4 * (int64_t)p : 0);
+            const CropXform cx = make_crop(c);
+            inside = crop_apply(cx, (c[1] - c[0]) >= (c[3] - c[2]), 1, u, v);
+        }
+        double *o = out + (int64_t)p * 3 * n;
+        o[i] = u;
+        o[n + i] = v;
+        o[2 * n + i] = z;
+        const int64_t t = (int64_t)p * n + i;
+        truth[t] = vis && inside;
+        if (truth_depth) truth_depth[t] = vis;
+        if (truth_crop) truth_crop[t] = inside;
+    }
+}
+
+int check_depth_args(const float *depth, int H, int W, int ylim, int xlim, int variant) {
+    ISPA_REQUIRE(depth != nullptr, "depth map pointer is null");
+    ISPA_REQUIRE(H > 0 && W > 0, "depth map shape (%d,%d) invalid", H, W);
+    ISPA_REQUIRE(ylim >= 1 && ylim <= H && xlim >= 1 && xlim <= W,
+                 "visibility gate (%d,%d) exceeds the depth map (%d,%d)", ylim, xlim, H, W);
+    ISPA_REQUIRE(variant == ISPA_VIS_A || variant == ISPA_VIS_B, "unknown visibility variant %d", variant);
+    return ISPA_OK;
+}
+
+// Poses per block: enough blocks to fill the chip, while re-using each loaded point.
+int pick_poses_per_block(int64_t n, int n_pose) {
+    const int64_t point_blocks = (n + kThreads - 1) / kThreads;
+    int ppb = 1;
+    while (ppb < 16 && point_blocks * ((n_pose + 2 * ppb - 1) / (2 * ppb)) >= 2048) ppb *= 2;
+    return ppb;
+}
+
+}  // namespace
+
+extern "C" int ispa_project(const double *pts, int64_t n, const double *cams, int n_pose, double *out,
+                            void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pts && cams && out, "null pointer");
+    const int ppb = pick_poses_per_block(n, n_pose);
+    dim3 grid(ispa::blocks_for(n, kThreads), (n_pose + ppb - 1) / ppb);
+    ISPA_REQUIRE(grid.y <= 65535, "too many poses per call (%d)", n_pose);
+    hipLaunchKernelGGL(project_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose,
+                       ppb, out);
+    return ispa::check_launch("project_kernel");
+}
+
+extern "C" int ispa_depth_visibility(const double *pt_render, int64_t n, int n_pose, const float *depth,
+                                     int depth_per_pose, int H, int W, int ylim, int xlim, double relax,
+                                     int variant, uint8_t *truth, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pt_render && truth, "null pointer");
+    if (int rc = check_depth_args(depth, H, W, ylim, xlim, variant)) return rc;
+    ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
+    dim3 grid(ispa::blocks_for(n, kThreads), n_pose);
+    if (variant == ISPA_VIS_A)
+        hipLaunchKernelGGL(depth_visibility_kernel<ISPA_VIS_A>, grid, dim3(kThreads), 0, (hipStream_t)stream,
+                           pt_render, n, n_pose, depth, depth_per_pose, H, W, ylim, xlim, relax, truth);
+    else
+        hipLaunchKernelGGL(depth_visibility_kernel<ISPA_VIS_B>, grid, dim3(kThreads), 0, (hipStream_t)stream,
+                           pt_render, n, n_pose, depth, depth_per_pose, H, W, ylim, xlim, relax, truth);
+    return ispa::check_launch("depth_visibility_kernel");
+}
+
+extern "C" int ispa_crop_remap(double *pt_render, int64_t n, int n_pose, const int32_t *crop,
+                               int crop_per_pose, int resize, uint8_t *truth, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pt_render && crop, "null pointer");
+    ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
+    dim3 grid(ispa::blocks_for(n, kThreads), n_pose);
+    hipLaunchKernelGGL(crop_remap_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pt_render, n, crop,
+                       crop_per_pose, resize, truth);
+    return ispa::check_launch("crop_remap_kernel");
+}
+
+extern "C" int ispa_project_prune(const double *pts, int64_t n, const double *cams, int n_pose,
+                                  const float *depth, int depth_per_pose, int H, int W, int ylim, int xlim,
+                                  double relax, int variant, const int32_t *crop, int crop_per_pose,
+                                  double *out, uint8_t *truth, uint8_t *truth_depth, uint8_t *truth_crop,
+                                  void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pts && cams && out && truth, "null pointer");
+    if (int rc = check_depth_args(depth, H, W, ylim, xlim, variant)) return rc;
+    const int ppb = pick_poses_per_block(n, n_pose);
+    dim3 grid(ispa::blocks_for(n, kThreads), (n_pose + ppb - 1) / ppb);
+    ISPA_REQUIRE(grid.y <= 65535, "too many poses per call (%d)", n_pose);
+    if (variant == ISPA_VIS_A)
+        hipLaunchKernelGGL(project_prune_kernel<ISPA_VIS_A>, grid, dim3(kThreads), 0, (hipStream_t)stream, pts,
+                           n, cams, n_pose, ppb, depth, depth_per_pose, H, W, ylim, xlim, relax, crop,
+                           crop_per_pose, out, truth, truth_depth, truth_crop);
+    else
+        hipLaunchKernelGGL(project_prune_kernel<ISPA_VIS_B>, grid, dim3(kThreads), 0, (hipStream_t)stream, pts,
+                           n, cams, n_pose, ppb, depth, depth_per_pose, H, W, ylim, xlim, relax, crop,
+                           crop_per_pose, out, truth, truth_depth, truth_crop);
+    return ispa::check_launch("project_prune_kernel");
+}

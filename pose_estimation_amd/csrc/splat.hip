@@ -1,0 +1,232 @@
+// Splat writers: proxy-optical-flow map, point depth map, packed z-buffer.
+//
+// The reference writes blocks sequentially in point order (make_disparity_syn.py:65-68,
+// io_utils.py:119-124), so each pixel ends up with the value of the LAST point covering it.
+// Here that is an integer atomicMax of (point index + 1) per pixel followed by a resolve pass,
+// which is order-independent and therefore deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// Bounds of the Python slice [c-r : c+r] on an axis of length `size` (negative values wrap once).
+__device__ __forceinline__ void py_slice(int c, int r, int size, int &lo, int &hi) {
+    lo = c - r;
+    hi = c + r;
+    if (lo < 0) {
+        lo += size;
+        if (lo < 0) lo = 0;
+    } else if (lo > size) {
+        lo = size;
+    }
+    if (hi < 0) {
+        hi += size;
+        if (hi < 0) hi = 0;
+    } else if (hi > size) {
+        hi = size;
+    }
+    if (hi < lo) hi = lo;
+}
+
+// astype(int) / int() of a float64 that is finite; out-of-int-range values are rejected.
+__device__ __forceinline__ bool to_int(double x, int &out) {
+    const double t = trunc(x);
+    if (!(t > -1.0e9 && t < 1.0e9)) return false;
+    out = (int)t;
+    return true;
+}
+
+__global__ __launch_bounds__(kThreads) void flow_owner_kernel(const double *__restrict__ uv1,
+                                                              const uint8_t *__restrict__ truth, int64_t n,
+                                                              int spread, int side,
+                                                              int32_t *__restrict__ owner) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int m = blockIdx.y;
+    if (i >= n) return;
+    if (!truth[(int64_t)m * n + i]) return;
+    const double *r = uv1 + (int64_t)m * 3 * n;
+    int u, v;
+    if (!to_int(r[i], u) || !to_int(r[n + i], v)) return;
+    int y0, y1, x0, x1;
+    py_slice(v, spread, side, y0, y1);
+    py_slice(u, spread, side, x0, x1);
+    int32_t *o = owner + (int64_t)m * side * side;
+    const int32_t tag = (int32_t)i + 1;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) atomicMax(&o[y * side + x], tag);
+}
+
+__global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__restrict__ uv1,
+                                                                const double *__restrict__ uv2, int64_t n,
+                                                                int side, const int32_t *__restrict__ owner,
+                                                                double *__restrict__ flow) {
+    const int pix = blockIdx.x * kThreads + threadIdx.x;
+    const int m = blockIdx.y;
+    if (pix >= side * side) return;
+    const int32_t o = owner[(int64_t)m * side * side + pix];
+    double2 val = make_double2(0.0, 0.0);
+    if (o > 0) {
+        const double *a = uv1 + (int64_t)m * 3 * n;
+        const double *b = uv2 + (int64_t)m * 3 * n;
+        const int64_t i = o - 1;
+        val.x = b[i] - a[i];
+        val.y = b[n + i] - a[n + i];
+    }
+    reinterpret_cast<double2 *>(flow)[(int64_t)m * side * side + pix] = val;
+}
+
+__global__ __launch_bounds__(kThreads) void depth_owner_kernel(const double *__restrict__ pt_render,
+                                                               int64_t n, int H, int W, int radius,
+                                                               int32_t *__restrict__ owner) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    int u, v;
+    if (!to_int(pt_render[i], u) || !to_int(pt_render[n + i], v)) return;
+    int y0, y1, x0, x1;
+    py_slice(v, radius, H, y0, y1);
+    py_slice(u, radius, W, x0, x1);
+    const int32_t tag = (int32_t)i + 1;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) atomicMax(&owner[(int64_t)y * W + x], tag);
+}
+
+__global__ __launch_bounds__(kThreads) void depth_resolve_kernel(const double *__restrict__ pt_render,
+                                                                 int64_t n, int64_t npix,
+                                                                 const int32_t *__restrict__ owner,
+                                                                 double *__restrict__ out) {
+    const int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pix >= npix) return;
+    const int32_t o = owner[pix];
+    out[pix] = o > 0 ? pt_render[2 * n + (o - 1)] : 0.0;
+}
+
+__device__ __forceinline__ bool zbuf_pixel(const double *__restrict__ r, int64_t n, int64_t i, int H, int W,
+                                           int &x, int &y, double &z) {
+    z = r[2 * n + i];
+    if (!to_int(r[i], x) || !to_int(r[n + i], y)) return false;
+    // z must be finite and positive; NaN fails the first comparison
+    return (z > 0.0) && (z < __builtin_inf()) && x >= 0 && x < W && y >= 0 && y < H;
+}
+
+__global__ __launch_bounds__(kThreads) void zbuffer_kernel(const double *__restrict__ pt_render, int64_t n,
+                                                           int H, int W, int radius,
+                                                           unsigned long long *__restrict__ packed) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= n) return;
+    int x, y;
+    double z;
+    if (!zbuf_pixel(pt_render + (int64_t)p * 3 * n, n, i, H, W, x, y, z)) return;
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint((float)z) << 32) | (unsigned long long)(uint32_t)i;
+    unsigned long long *img = packed + (int64_t)p * H * W;
+    const int y0 = max(y - radius, 0), y1 = min(y + radius, H - 1);
+    const int x0 = max(x - radius, 0), x1 = min(x + radius, W - 1);
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) atomicMin(&img[(int64_t)yy * W + xx], key);
+}
+
+__global__ __launch_bounds__(kThreads) void zbuffer_resolve_kernel(const unsigned long long *__restrict__ packed,
+                                                                   int64_t total, int32_t *__restrict__ winner,
+                                                                   float *__restrict__ depth) {
+    const int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (pix >= total) return;
+    const unsigned long long k = packed[pix];
+    const bool empty = k == ~0ull;
+    if (winner) winner[pix] = empty ? -1 : (int32_t)(uint32_t)(k & 0xffffffffull);
+    if (depth) depth[pix] = empty ? __builtin_inff() : __uint_as_float((uint32_t)(k >> 32));
+}
+
+__global__ __launch_bounds__(kThreads) void zbuffer_visibility_kernel(const double *__restrict__ pt_render,
+                                                                      int64_t n, const float *__restrict__ depth,
+                                                                      int H, int W, double relax,
+                                                                      uint8_t *__restrict__ truth) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int p = blockIdx.y;
+    if (i >= n) return;
+    int x, y;
+    double z;
+    bool vis = zbuf_pixel(pt_render + (int64_t)p * 3 * n, n, i, H, W, x, y, z);
+    if (vis) vis = (z - (double)depth[((int64_t)p * H + y) * W + x]) <= relax;
+    truth[(int64_t)p * n + i] = vis;
+}
+
+}  // namespace
+
+extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
+                               int n_map, int spread, int side, int32_t *owner_ws, double *flow,
+                               void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_map >= 0 && n < (1ll << 31) - 1, "bad point count");
+    ISPA_REQUIRE(side > 0 && side <= 16384 && spread >= 0 && spread <= 64, "bad side/spread");
+    if (n_map == 0) return ISPA_OK;
+    ISPA_REQUIRE(owner_ws && flow, "null pointer");
+    ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)side * side;
+    ISPA_HIP(hipMemsetAsync(owner_ws, 0, npix * n_map * sizeof(int32_t), s));
+    if (n > 0) {
+        ISPA_REQUIRE(uv1 && uv2 && truth, "null pointer");
+        hipLaunchKernelGGL(flow_owner_kernel, dim3(ispa::blocks_for(n, kThreads), n_map), dim3(kThreads), 0, s,
+                           uv1, truth, n, spread, side, owner_ws);
+        if (int rc = ispa::check_launch("flow_owner_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(flow_resolve_kernel, dim3(ispa::blocks_for((int64_t)npix, kThreads), n_map),
+                       dim3(kThreads), 0, s, uv1, uv2, n, side, owner_ws, flow);
+    return ispa::check_launch("flow_resolve_kernel");
+}
+
+extern "C" int ispa_point_depth_splat(const double *pt_render, int64_t n, int H, int W, int radius,
+                                      int32_t *owner_ws, double *depth_out, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n < (1ll << 31) - 1, "bad point count");
+    ISPA_REQUIRE(H > 0 && W > 0 && radius >= 0 && radius <= 64, "bad shape/radius");
+    ISPA_REQUIRE(owner_ws && depth_out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t npix = (int64_t)H * W;
+    ISPA_HIP(hipMemsetAsync(owner_ws, 0, (size_t)npix * sizeof(int32_t), s));
+    if (n > 0) {
+        ISPA_REQUIRE(pt_render, "null pointer");
+        hipLaunchKernelGGL(depth_owner_kernel, dim3(ispa::blocks_for(n, kThreads)), dim3(kThreads), 0, s,
+                           pt_render, n, H, W, radius, owner_ws);
+        if (int rc = ispa::check_launch("depth_owner_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(depth_resolve_kernel, dim3(ispa::blocks_for(npix, kThreads)), dim3(kThreads), 0, s,
+                       pt_render, n, npix, owner_ws, depth_out);
+    return ispa::check_launch("depth_resolve_kernel");
+}
+
+extern "C" int ispa_zbuffer(const double *pt_render, int64_t n, int n_pose, int H, int W, int radius,
+                            uint64_t *packed, int32_t *winner, float *depth, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n < (1ll << 32) && n_pose >= 0, "bad point count");
+    ISPA_REQUIRE(H > 0 && W > 0 && radius >= 0 && radius <= 64, "bad shape/radius");
+    if (n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(packed, "null pointer");
+    ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)n_pose * H * W;
+    ISPA_HIP(hipMemsetAsync(packed, 0xff, (size_t)total * sizeof(uint64_t), s));
+    if (n > 0) {
+        ISPA_REQUIRE(pt_render, "null pointer");
+        hipLaunchKernelGGL(zbuffer_kernel, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads), 0, s,
+                           pt_render, n, H, W, radius, (unsigned long long *)packed);
+        if (int rc = ispa::check_launch("zbuffer_kernel")) return rc;
+    }
+    if (winner || depth) {
+        hipLaunchKernelGGL(zbuffer_resolve_kernel, dim3(ispa::blocks_for(total, kThreads)), dim3(kThreads), 0,
+                           s, (const unsigned long long *)packed, total, winner, depth);
+        return ispa::check_launch("zbuffer_resolve_kernel");
+    }
+    return ISPA_OK;
+}
+
+extern "C" int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, const float *depth,
+                                       int H, int W, double relax, uint8_t *truth, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pt_render && depth && truth, "null pointer");
+    ISPA_REQUIRE(H > 0 && W > 0, "bad shape");
+    ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
+    hipLaunchKernelGGL(zbuffer_visibility_kernel, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads),
+                       0, (hipStream_t)stream, pt_render, n, depth, H, W, relax, truth);
+    return ispa::check_launch("zbuffer_visibility_kernel");
+}

@@ -1,0 +1,84 @@
+"""Proxy optical flow ("disparity") maps between a render and the same model turned by (10, 10).
+
+Drop-in for data_creator/make_disparity_syn.py: `make_disparity_maps` is the data-in /
+data-out core of the per-image body (lines 44-68), batched over images; `make_disparity`
+keeps the script's directory-walking entry point (lines 17-70).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _abi, _device as dv, io_utils, pt2render, run_proj
+
+FLOW_SIDE = 224          # make_disparity_syn.py:61
+SPREAD = 2               # make_disparity_syn.py:63
+POSE_STEP = (10.0, 10.0)  # make_disparity_syn.py:49-50
+
+
+def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
+    """make_disparity_syn.py:55-68 for already projected points.
+
+    uv1, uv2 (n_map,3,N) or (3,N) crop coordinates at pose 1 / pose 2, truth (n_map,N) = truth_1.
+    Returns flow (n_map,side,side,2) float64 (or (side,side,2))."""
+    as_tensor = dv.is_tensor(uv1)
+    a = dv.to_dev(uv1, torch.float64)
+    b = dv.to_dev(uv2, torch.float64)
+    t = dv.to_dev(truth, torch.uint8)
+    single = a.dim() == 2
+    if single:
+        a, b, t = a[None], b[None], t[None]
+    n_map, _, n = a.shape
+    owner = dv.empty((n_map, side * side), torch.int32)
+    flow = dv.empty((n_map, side, side, 2), torch.float64)
+    _abi.check(_abi.lib.ispa_flow_splat(dv.ptr(a), dv.ptr(b), dv.ptr(t), n, n_map, int(spread), int(side),
+                                        dv.ptr(owner), dv.ptr(flow), dv.stream_ptr()))
+    if single:
+        flow = flow[0]
+    return dv.back(flow, as_tensor)
+
+
+def make_disparity_maps(key_3d, params, depth_maps, crop_params):
+    """Body of make_disparity for a batch of renders of ONE model.
+
+    key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
+    depth_maps (n_map,540,960) f32 (the first pose's depth image, used for both poses as the
+    reference does); crop_params (n_map,4).  Only the first pose's truth masks the points.
+    Returns flow (n_map,224,224,2) float64, numpy unless key_3d is a device tensor."""
+    as_tensor = dv.is_tensor(key_3d)
+    params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    n_map = params.shape[0]
+    cams1 = np.stack([run_proj.camera_from_params(p) for p in params])
+    more = params.copy()
+    more[:, 0] += POSE_STEP[0]
+    more[:, 1] += POSE_STEP[1]
+    cams2 = np.stack([run_proj.camera_from_params(p) for p in more])
+    pts = dv.to_dev(key_3d, torch.float64)
+    depth = dv.to_dev(depth_maps, torch.float32)
+    if depth.dim() == 2:
+        depth = depth[None]
+    crops = np.asarray(crop_params).reshape(n_map, 4)
+    truth1, uv1 = run_proj.project_prune(pts, cams1, depth, crops)
+    _, uv2 = run_proj.project_prune(pts, cams2, depth, crops)
+    flow = flow_splat(uv1, uv2, truth1)
+    return dv.back(flow, as_tensor)
+
+
+def make_disparity(class_name, key_3d, image_dir, depth_dir, save_dir, template_model, batch=64):
+    """make_disparity_syn.py:17-70 with the data locations passed in instead of read from
+    global_variables: for every render of `template_model` under image_dir, write
+    <save_dir>/<image stem>.npy = (224,224,2) float64 flow.  Returns the number of maps written."""
+    del class_name
+    os.makedirs(save_dir, exist_ok=True)
+    images = sorted(x for x in os.listdir(image_dir) if template_model in x)
+    for start in range(0, len(images), batch):
+        chunk = images[start:start + batch]
+        dicts = [io_utils.get_params_from_syn_file(x) for x in chunk]
+        params = [[d["azimuth"], d["elevation"], d["tilt"], d["rho"]] for d in dicts]
+        crops = [d["crop_params"] for d in dicts]
+        depth = np.stack([run_proj.get_depthmap_from_exr(os.path.join(depth_dir, io_utils.img_to_depth_file(x)))
+                          for x in chunk])
+        flows = make_disparity_maps(key_3d, params, depth, crops)
+        for name, flow in zip(chunk, flows):
+            np.save(os.path.join(save_dir, name.split(".")[0]), flow)
+    return len(images)

@@ -1,0 +1,102 @@
+"""Projection orchestration with the reference's entry points.
+
+Drop-in for data_creator/render_wt_pt_proj/run_proj.py:24-57 (get_3d_to_2d, prune_pts,
+get_depthmap_from_exr) plus batched forms for pose sweeps.  Mesh sampling (get_keypoints,
+run_proj.py:15-22) needs trimesh and stays outside: callers pass the (N,3) point array.
+"""
+import numpy as np
+import torch
+
+from . import _abi, _device as dv, pt2render, variables
+from .variables import VIS_XLIM, VIS_YLIM
+
+
+def camera_from_params(params):
+    ext = pt2render.ex_camera_matrix(params[0], params[1], params[2], params[3])
+    return pt2render.get_camera_matrix(variables.INTRINSIC_CAMERA_MATRIX, ext, variables.WORLD_MATRIX)
+
+
+def get_3d_to_2d(model_pts, params):
+    """run_proj.py:24-31 -- params = [azimuth, elevation, tilt, distance] -> (3,N)."""
+    return pt2render.get_render_location(model_pts, camera_from_params(params))
+
+
+def get_depthmap_from_exr(file_name):
+    """run_proj.py:49-57 reads the 'R' channel of a Blender EXR.  This build reads the same
+    (H,W) float32 image from a .npy cache written next to it (file_name or file_name + '.npy');
+    decoding EXR itself needs the OpenEXR package."""
+    for cand in (file_name, file_name + ".npy"):
+        if cand.endswith(".npy"):
+            try:
+                return np.load(cand).astype(np.float32, copy=False)
+            except FileNotFoundError:
+                continue
+    try:
+        import Imath
+        import OpenEXR
+    except ImportError as exc:
+        raise ImportError(f"no .npy cache for {file_name} and OpenEXR is not installed") from exc
+    handle = OpenEXR.InputFile(file_name)
+    window = handle.header()["dataWindow"]
+    shape = (window.max.y - window.min.y + 1, window.max.x - window.min.x + 1)
+    raw = handle.channel("R", Imath.PixelType(Imath.PixelType.FLOAT))
+    return np.frombuffer(raw, dtype=np.float32).reshape(shape)
+
+
+def _depth_array(depth):
+    return get_depthmap_from_exr(depth) if isinstance(depth, str) else depth
+
+
+def prune_pts(pt_array, depth_map_name, crop=False, crop_params=None):
+    """run_proj.py:33-46 -- depth visibility (variant A) and optional crop test + remap.
+
+    depth_map_name may be a file name (see get_depthmap_from_exr) or the (H,W) float32 array
+    itself.  With crop=True the caller's pt_array is rewritten in crop coordinates, exactly as
+    the reference does, and returned as the second value."""
+    depth_map = _depth_array(depth_map_name)
+    depth_truth, depth_pts = pt2render.depth_visibility_array(pt_array, depth_map)
+    if crop:
+        crop_truth, crop_pts = pt2render.crop_visibility_array(pt_array, crop_params)
+    else:
+        crop_truth = torch.ones_like(depth_truth, dtype=torch.float64) if dv.is_tensor(depth_truth) \
+            else np.ones(depth_truth.shape)
+        crop_pts = depth_pts
+    return crop_truth * depth_truth, crop_pts
+
+
+def project_prune(model_pts, cams, depth_maps, crop_params=None, variant="A", error_relaxation=None,
+                  want_parts=False):
+    """One-launch batched get_3d_to_2d + prune_pts over n_pose cameras.
+
+    model_pts (N,3); cams (n_pose,3,4); depth_maps (H,W) shared or (n_pose,H,W);
+    crop_params None, one [top,bottom,left,right] or (n_pose,4).
+    Returns (truth (n_pose,N) bool, pts (n_pose,3,N) f64[, depth_truth, crop_truth])."""
+    as_tensor = dv.is_tensor(model_pts)
+    pts = dv.to_dev(model_pts, torch.float64)
+    cams_t = dv.to_dev(cams, torch.float64).reshape(-1, 3, 4)
+    depth = dv.to_dev(depth_maps, torch.float32)
+    per_pose = 1 if depth.dim() == 3 else 0
+    h, w = depth.shape[-2:]
+    n, n_pose = pts.shape[0], cams_t.shape[0]
+    if per_pose and depth.shape[0] != n_pose:
+        raise ValueError("need one depth map per pose or a single shared one")
+    crop_t, crop_per_pose = None, 0
+    if crop_params is not None:
+        crop_t = dv.to_dev(np.asarray(crop_params).reshape(-1, 4), torch.int32)
+        crop_per_pose = 1 if crop_t.shape[0] > 1 else 0
+        if crop_per_pose and crop_t.shape[0] != n_pose:
+            raise ValueError("need one crop per pose or a single shared one")
+    if error_relaxation is None:
+        error_relaxation = 0.15 if variant == "A" else 0.05
+    out = dv.empty((n_pose, 3, n), torch.float64)
+    truth = dv.empty((n_pose, n), torch.uint8)
+    td = dv.empty((n_pose, n), torch.uint8) if want_parts else None
+    tc = dv.empty((n_pose, n), torch.uint8) if want_parts else None
+    _abi.check(_abi.lib.ispa_project_prune(
+        dv.ptr(pts), n, dv.ptr(cams_t), n_pose, dv.ptr(depth), per_pose, h, w, min(VIS_YLIM, h),
+        min(VIS_XLIM, w), float(error_relaxation), _abi.VIS_A if variant == "A" else _abi.VIS_B,
+        dv.ptr(crop_t), crop_per_pose, dv.ptr(out), dv.ptr(truth), dv.ptr(td), dv.ptr(tc), dv.stream_ptr()))
+    res = [dv.back(truth.bool(), as_tensor), dv.back(out, as_tensor)]
+    if want_parts:
+        res += [dv.back(td.bool(), as_tensor), dv.back(tc.bool(), as_tensor)]
+    return tuple(res)

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares, and rejects bad calls
+before touching a device."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(HERE, "include", "ispa_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ispa_[a-z0-9_]+)\s*\(", text))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from pose_estimation_amd import _abi
+    names = _declared()
+    assert names == set(_abi.SIGNATURES), names ^ set(_abi.SIGNATURES)
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _abi.lib.ispa_abi_version() == 1
+
+
+def test_argument_checks_do_not_need_a_gpu():
+    from pose_estimation_amd import _abi
+    assert _abi.lib.ispa_nn_workspace_bytes(1, 128, 4096, 4096, 1) > 0
+    assert _abi.lib.ispa_nn_workspace_bytes(1, 128, 4096, 4096, 9) == 0
+    rc = _abi.lib.ispa_nn_topk(None, None, 0, 1, 8, 16, 16, 9, 1, None, None, None, 0, None, None)
+    assert rc == -1 and b"k = 9" in _abi.lib.ispa_last_error()
+    rc = _abi.lib.ispa_depth_visibility(1, 10, 1, 1, 0, 100, 100, 540, 950, 0.15, 0, 1, None)
+    assert rc == -1 and b"gate" in _abi.lib.ispa_last_error()
+    rc = _abi.lib.ispa_project(None, 0, None, 0, None, None)
+    assert rc == 0                                           # empty input is a no-op
+
+
+def test_host_helpers_without_gpu():
+    import numpy as np
+    from pose_estimation_amd import correspondence, dense_pointset, io_utils, pt2render
+    from oracle import geometry as og, keypoints as okp
+    assert np.array_equal(pt2render.ex_camera_matrix(30, 10, 0, 3), og.ex_camera_matrix(30, 10, 0, 3))
+    poses = np.array([[30, 10, 0, 3], [200, -5, 12, 2.5]], dtype=float)
+    want = np.stack([og.camera_from_params(p) for p in poses])
+    assert np.allclose(pt2render.camera_matrices(poses), want, rtol=1e-13, atol=1e-12)
+    name = "04256520_1fd45c57ab27cb6cea65c47b660136e7_a90@179_e0@236_t5@000_d3@000_199_343_385_575_.jpg"
+    d = io_utils.get_params_from_file("a/b/" + name)
+    assert d == okp.get_params_from_syn_file(name) and d["tilt"] == -5.0
+    assert io_utils.img_to_depth_file(name) == okp.img_to_depth_file(name)
+    assert os.path.basename(io_utils.get_final_file_name(d)) == name == okp.render_file_name(d)
+    assert io_utils.get_depth_map_name(d) == okp.depth_map_name(d)
+    rs = np.random.RandomState(0)
+    for cls, k in (("chair", 10), ("bed", 10), ("sofa", 14), ("table", 8), ("swivelchair", 13)):
+        a = rs.randn(k, 3)
+        coords = dense_pointset.get_additional_coords_keypoint_5(a.T, cls)
+        assert np.array_equal(dense_pointset.dense_skeleton(coords, cls), okp.dense_skeleton_3d(a, cls))
+        assert np.array_equal(dense_pointset.dense_skeleton(coords[:2], cls, dim=2), okp.dense_skeleton_2d(coords[:2], cls))
+    xy = rs.uniform(-20, 260, (14, 2))
+    assert np.array_equal(correspondence.knn_inds_to_grid(xy), okp.knn_inds_to_grid(xy))
+    ind = rs.randint(1, 3137, (2, 1, 50))
+    assert np.array_equal(correspondence.ind2coord(ind, 56), okp.ind2coord(ind, 56))
+    stored = np.stack([rs.uniform(0, 360, 500), rs.uniform(-20, 20, 500), rs.uniform(-20, 20, 500)], 1)
+    for view in ([0, 10, 0], [359, 0, 0], [120, 10, 0], [181, -3, 4]):
+        assert correspondence.nearest_view(view, stored) == okp.nearest_view(view, stored)

@@ -1,0 +1,418 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars: integer / boolean / index results bit-exact; float64 z and flow values bit-exact against
+the oracle's fixed-order twin and <= 1e-12 relative against the imported reference's numpy;
+float32 distances and correlation maps within 1e-4 relative (tolerances written at each assert).
+"""
+import numpy as np
+import pytest
+
+from oracle import cnative, correlation as ocorr, disparity as odisp, geometry as og, keypoints as okp
+from oracle import nn as onn, zbuffer as ozb
+
+pytestmark = pytest.mark.gpu
+
+ANCHORS = ["bed", "chair", "sofa_b", "sofa", "table"]
+
+
+@pytest.fixture(scope="module")
+def pea():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import pose_estimation_amd as p
+    return p
+
+
+# ---------------------------------------------------------------- geometry
+def test_camera_host_functions(pea, golden_geometry):
+    z = golden_geometry
+    for pose, e, p, r in zip(z["g1_poses"], z["g1_E"], z["g1_P"], z["g1_R"]):
+        assert np.array_equal(pea.pt2render.rot_three_angles(pose[0], pose[1], pose[2]), r)
+        assert np.array_equal(pea.pt2render.ex_camera_matrix(*pose), e)
+        assert np.array_equal(pea.run_proj.camera_from_params(pose), p)
+    batch = pea.pt2render.camera_matrices(z["g1_poses"])
+    assert np.allclose(batch, z["g1_P"], rtol=1e-13, atol=1e-12)
+
+
+def test_projection_golden(pea, golden_geometry):
+    z = golden_geometry
+    cam = z["g2_big_cam"]
+    for name in ANCHORS:
+        got = pea.pt2render.get_render_location(z[f"g2_anchor_{name}"], cam)
+        assert np.array_equal(got, z[f"g2_anchor_{name}_render"])
+    got = pea.pt2render.get_render_location(z["g2_obj_vertices"], cam)
+    assert np.array_equal(got[:2], z["g2_obj_render"][:2])
+    assert np.allclose(got[2], z["g2_obj_render"][2], rtol=1e-12, atol=0)
+    assert np.array_equal(got, cnative.project_fma(z["g2_obj_vertices"], cam))     # bit-exact twin
+
+
+def test_projection_100k_bit_exact(pea, golden_geometry):
+    z = golden_geometry
+    cam = z["g2_big_cam"]
+    big = np.random.RandomState(0).uniform(-0.4, 0.4, (100000, 3))
+    got = pea.pt2render.get_render_location(big, cam)
+    assert np.array_equal(got, cnative.project_fma(big, cam))
+    sub = z["g2_big_sub_index"]
+    assert np.array_equal(got[:2, sub], z["g2_big_sub_render"][:2])
+    assert np.allclose(got[2, sub], z["g2_big_sub_render"][2], rtol=1e-12, atol=0)
+    import hashlib
+    digest = hashlib.sha256(np.ascontiguousarray(got[:2]).tobytes()).digest()
+    assert np.array_equal(np.frombuffer(digest, dtype=np.uint8), z["g2_big_uv_sha256"])
+
+
+def test_projection_batched_and_ragged(pea, golden_geometry):
+    z = golden_geometry
+    cams = z["g1_P"][:37]
+    for n in (0, 1, 255, 257, 1000):
+        pts = np.random.RandomState(n).uniform(-0.5, 0.5, (n, 3))
+        got = pea.pt2render.get_render_location(pts, cams)
+        assert got.shape == (37, 3, n)
+        for p in (0, 17, 36):
+            assert np.array_equal(got[p], cnative.project_fma(pts, cams[p]))
+
+
+@pytest.mark.parametrize("tag", ["near", "std", "tilt"])
+@pytest.mark.parametrize("dname", ["surface", "const", "plane"])
+def test_depth_visibility_golden(pea, golden_geometry, tag, dname):
+    z = golden_geometry
+    r = z[f"g3_{tag}_render"]
+    d = np.full((540, 960), 3.0, np.float32) if dname == "const" else z[f"g3_{tag}_depth_{dname}"]
+    arr = r.copy()
+    ta, same = pea.pt2render.depth_visibility_array(arr, d)
+    assert same is arr and np.array_equal(arr, r)
+    assert ta.dtype == np.bool_ and np.array_equal(ta, z[f"g3_{tag}_{dname}_truth_a"])
+    tb, pruned = pea.pt2render_b.depth_visibility_array(r.copy(), d)
+    assert np.array_equal(tb, z[f"g3_{tag}_{dname}_truth_b"])
+    assert np.array_equal(pruned, z[f"g3_{tag}_{dname}_pruned_b"])
+
+
+def test_depth_visibility_edges(pea, golden_geometry):
+    z = golden_geometry
+    r, d = z["g3_edge_render"], z["g3_edge_depth"]
+    assert np.array_equal(pea.pt2render.depth_visibility_array(r.copy(), d)[0], z["g3_edge_truth_a"])
+    assert np.array_equal(pea.pt2render_b.depth_visibility_array(r.copy(), d)[0], z["g3_edge_truth_b"])
+    bad = np.array([[np.nan, np.inf, 1e300, 100.0], [10.0, 10.0, 10.0, np.nan], [2.5] * 4])
+    assert not pea.pt2render.depth_visibility_array(bad, d)[0].any()
+
+
+@pytest.mark.parametrize("tag", ["wide", "tall", "square", "odd"])
+def test_crop_remap_golden(pea, golden_geometry, tag):
+    z = golden_geometry
+    arr = z["g3_std_render"].copy()
+    t, same = pea.pt2render.crop_visibility_array(arr, z[f"g4_{tag}_crop"].tolist())
+    assert same is arr                                     # the caller's array is rewritten
+    assert np.array_equal(t, z[f"g4_{tag}_truth"])
+    assert np.array_equal(arr, z[f"g4_{tag}_render"])
+
+
+def test_crop_noresize(pea, golden_geometry):
+    z = golden_geometry
+    arr = z["g3_std_render"].copy()
+    t, _ = pea.pt2render.crop_visibility_array(arr, [100, 400, 300, 700], resize=False)
+    assert np.array_equal(t, z["g4_noresize_truth"]) and np.array_equal(arr, z["g4_noresize_render"])
+
+
+def test_prune_pts_and_fused(pea, golden_geometry):
+    z = golden_geometry
+    pts, params = z["g3_std_pts"], z["g3_std_params"].tolist()
+    depth = z["g3_std_depth_surface"]
+    crop = [100, 400, 300, 700]
+    want_r = og.get_3d_to_2d(pts, params)
+    want_t, want_c = og.prune_pts(want_r, depth, crop=True, crop_params=crop)
+    got_r = pea.run_proj.get_3d_to_2d(pts, params)
+    got_t, got_c = pea.run_proj.prune_pts(got_r, depth, crop=True, crop_params=crop)
+    assert got_c is got_r and np.array_equal(got_t, want_t) and np.array_equal(got_c[:2], want_c[:2])
+    # no crop: float truth like the reference (ones * bool)
+    t2, _ = pea.run_proj.prune_pts(pea.run_proj.get_3d_to_2d(pts, params), depth)
+    assert np.array_equal(t2, og.prune_pts(og.get_3d_to_2d(pts, params), depth)[0])
+    # fused kernel, several poses, per-pose depth and crop
+    poses = [params, [200.0, -5.0, 12.0, 2.0], [30.0, 10.0, 0.0, 1.1]]
+    cams = np.stack([og.camera_from_params(p) for p in poses])
+    depths = np.stack([z["g3_std_depth_surface"], z["g3_tilt_depth_surface"], z["g3_near_depth_surface"]])
+    crops = np.array([crop, [50, 500, 400, 600], [101, 388, 297, 641]])
+    for variant in ("A", "B"):
+        t, c, td, tc = pea.run_proj.project_prune(pts, cams, depths, crops, variant=variant, want_parts=True)
+        for p in range(3):
+            r = cnative.project_fma(pts, cams[p])
+            vis = (og.depth_visibility_array_a if variant == "A" else og.depth_visibility_array_b)(r, depths[p])[0]
+            ct, rc = og.crop_visibility_array(r, crops[p].tolist())
+            assert np.array_equal(td[p], vis) and np.array_equal(tc[p], ct)
+            assert np.array_equal(t[p], vis & ct) and np.array_equal(c[p], rc)
+
+
+@pytest.mark.parametrize("name", ANCHORS)
+def test_get_render_array_variant_b(pea, golden_disparity, golden_geometry, name):
+    z = golden_disparity
+    fd = {"azimuth": 120.0, "elevation": 10.0, "tilt": 0.0, "rho": 2.2, "crop_params": [60, 480, 250, 720]}
+    truth, crop_pts = pea.io_utils.get_render_array(fd, golden_geometry[f"g2_anchor_{name}"], z[f"rb_{name}_depth"])
+    assert np.array_equal(truth, z[f"rb_{name}_truth"])
+    assert np.array_equal(crop_pts[:2], z[f"rb_{name}_crop_pts"][:2])
+    assert np.allclose(crop_pts[2], z[f"rb_{name}_crop_pts"][2], rtol=1e-12, atol=0)
+
+
+def test_get_pt_and_grid_indices(pea, golden_disparity, golden_geometry):
+    name = "03001627_13fdf00cde077f562f6f52615fb75fca_a120@000_e10@000_t0@000_d2@200_60_480_250_720_.jpg"
+    anchors = golden_geometry["g2_anchor_chair"]
+    depth = golden_disparity["rb_chair_depth"]
+    got = pea.correspondence.get_pt(anchors, name, depth)
+    want = okp.get_pt(anchors, name, depth)
+    assert got.shape == (1, 10, 3) and np.array_equal(got, want)
+    assert np.array_equal(pea.correspondence.knn_inds_to_grid(got[0, :, :2]), okp.knn_inds_to_grid(want[0, :, :2]))
+
+
+# ---------------------------------------------------------------- splat writers
+@pytest.mark.parametrize("tag", ["cloud", "mesh", "edge"])
+def test_make_disparity_golden(pea, golden_disparity, tag):
+    z = golden_disparity
+    flow = pea.disparity.make_disparity_maps(z[f"{tag}_pts"], z[f"{tag}_params"], z[f"{tag}_depth"], z[f"{tag}_crop"])
+    assert flow.shape == (1, 224, 224, 2) and flow.dtype == np.float64
+    assert np.array_equal(flow[0], z[f"{tag}_flow"])
+
+
+def test_make_disparity_batch_100k(pea):
+    rs = np.random.RandomState(0)
+    pts = rs.uniform(-0.4, 0.4, (100000, 3))
+    params = np.array([[30.0, 10.0, 0.0, 3.0], [250.0, 25.0, 5.0, 2.6]])
+    depths, crops = [], []
+    for p in params:
+        r = og.get_3d_to_2d(pts, p)
+        d = ozb.zbuffer(r, 540, 960, radius=2)[2]
+        d[~np.isfinite(d)] = 20.0
+        depths.append(d.astype(np.float32))
+        t = og.depth_visibility_array_a(r, depths[-1])[0]
+        crops.append([int(r[1, t].min()) - 3, int(r[1, t].max()) + 3, int(r[0, t].min()) - 3, int(r[0, t].max()) + 3])
+    got = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
+    for m in range(2):
+        want = odisp.make_disparity_core(pts, params[m].tolist(), depths[m], crops[m])
+        assert np.array_equal(got[m], want)
+        assert np.count_nonzero(want) > 20000
+    # determinism of the atomic owner pass: two more runs give the same bytes
+    again = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
+    assert np.array_equal(got, again)
+
+
+def test_flow_splat_slice_semantics(pea):
+    uv = np.array([[0, 1, 2, 223, 230, -5, 100, 50], [50, 50, 50, 223, 10, 60, -3, 50], [1.0] * 8])
+    uv2 = uv + np.array([[1.5], [-2.0], [0.0]]) * np.arange(1, 9)
+    truth = np.array([1, 1, 1, 1, 1, 1, 1, 0], dtype=bool)
+    got = pea.disparity.flow_splat(uv, uv2, truth)
+    keep = truth
+    want = odisp.splat_flow_literal(uv[:, keep], (uv2 - uv)[:, keep])
+    assert np.array_equal(got, want)
+    assert not got[48:52, 48:52].any()            # the masked point wrote nothing
+    empty = pea.disparity.flow_splat(np.zeros((3, 0)), np.zeros((3, 0)), np.zeros(0, bool))
+    assert empty.shape == (224, 224, 2) and not empty.any()
+
+
+def test_point_depth_splat(pea, golden_disparity):
+    z = golden_disparity
+    assert np.array_equal(pea.io_utils.get_pt_depth_map(z["ptdepth_render"]), z["ptdepth_map"])
+
+
+def test_zbuffer(pea, golden_geometry):
+    r = golden_geometry["g3_near_render"]
+    for radius in (0, 2):
+        key, win, depth = ozb.zbuffer(r, 540, 960, radius=radius)
+        got = pea.zbuffer.zbuffer(r, (540, 960), radius=radius)
+        assert np.array_equal(got["winner"], win)
+        assert np.array_equal(got["depth"], depth)
+        assert np.array_equal(got["packed"].view(np.uint64), key)
+        vis = pea.zbuffer.visibility(r, got["depth"], relax=0.01)
+        assert np.array_equal(vis, ozb.zbuffer_visibility(r, depth, relax=0.01))
+    # batched over poses
+    rr = np.stack([golden_geometry["g3_near_render"], golden_geometry["g3_std_render"]])
+    got = pea.zbuffer.zbuffer(rr, (540, 960))
+    assert np.array_equal(got["winner"][1], ozb.zbuffer(rr[1], 540, 960)[1])
+
+
+# ---------------------------------------------------------------- dense nearest neighbour
+def _nn_check(pea, q, r, k, bf16=False, index_base=1):
+    import torch
+    b = q.shape[0]
+    if bf16:
+        qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+        rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
+        dist, ind, st = pea.correspondence.dense_nn(qd, rd, k, index_base, return_stats=True)
+        dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
+        q, r = cnative.round_bf16(q), cnative.round_bf16(r)
+    else:
+        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True)
+    assert ind.dtype == np.int32 and dist.dtype == np.float32
+    for i in range(b):
+        want_i, want_d = cnative.nn_exact(q[i].reshape(q.shape[1], -1), r[i].reshape(r.shape[1], -1), k, index_base)
+        assert np.array_equal(ind[i], want_i), f"pair {i}: {np.sum(ind[i] != want_i)} index mismatches"
+        scale = (q[i].reshape(q.shape[1], -1).astype(np.float64) ** 2).sum(0)[None, :] + 1.0
+        finite = np.isfinite(want_d)
+        # squared distances: 1e-4 relative, plus the rounding floor of the norm expansion
+        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]) + 2e-6 * np.broadcast_to(scale, want_d.shape)[finite])
+        assert np.all(np.isinf(dist[i][~finite]))
+    return st
+
+
+def _unit(rs, shape):
+    x = rs.randn(*shape).astype(np.float32)
+    return x / np.sqrt((x ** 2).sum(1, keepdims=True))
+
+
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_nn_small_ragged(pea, k):
+    rs = np.random.RandomState(k)
+    for (b, c, nq, nr) in ((1, 128, 300, 333), (3, 24, 130, 517), (2, 7, 64, 9), (1, 33, 1, 1025)):
+        _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), k)
+
+
+def test_nn_fewer_refs_than_k(pea):
+    rs = np.random.RandomState(3)
+    _nn_check(pea, _unit(rs, (1, 16, 50)), _unit(rs, (1, 16, 3)), 5)
+
+
+def test_nn_ties_and_duplicates(pea):
+    rs = np.random.RandomState(9)
+    q = _unit(rs, (2, 128, 256))
+    r = _unit(rs, (2, 128, 512))
+    r[:, :, 300] = r[:, :, 17]            # exact duplicate references: lowest index must win
+    r[:, :, 450] = r[:, :, 17]
+    q[:, :, 5] = r[:, :, 17]
+    q[:, :, 6] = r[:, :, 17]
+    r[0, :, 100:164] = r[0, :, 0:1]       # a block of 65 identical references
+    st = _nn_check(pea, q, r, 1)
+    assert st["exact_path_queries"] >= 2   # the duplicates must have gone through the float64 pass
+    _nn_check(pea, q, r, 5)
+    # degenerate input: every reference identical -> every query ambiguous
+    r2 = np.repeat(r[:, :, :1], 200, axis=2)
+    st = _nn_check(pea, q, r2, 1)
+    assert st["exact_path_queries"] == 2 * 256
+
+
+def test_nn_near_ties_below_rounding(pea):
+    # references that differ from each other by ~1e-7: the filter cannot order them, the exact pass must
+    rs = np.random.RandomState(21)
+    q = _unit(rs, (1, 128, 128))
+    r = _unit(rs, (1, 128, 256))
+    base = r[0, :, 40].copy()
+    for t in range(41, 60):
+        r[0, :, t] = base
+        r[0, t % 128, t] = np.nextafter(base[t % 128], np.float32(2.0))
+    q[0, :, 0] = base
+    _nn_check(pea, q, r, 1)
+    _nn_check(pea, q, r, 5)
+
+
+def test_nn_unnormalised_and_index_base(pea):
+    rs = np.random.RandomState(4)
+    q = (rs.randn(2, 64, 200) * 3.0).astype(np.float32)
+    r = (rs.randn(2, 64, 700) * rs.uniform(0.1, 5.0, (1, 1, 700))).astype(np.float32)
+    _nn_check(pea, q, r, 1, index_base=0)
+    _nn_check(pea, q, r, 5, index_base=0)
+
+
+def test_nn_nchw_layout_and_one_based(pea):
+    rs = np.random.RandomState(6)
+    f1 = _unit(rs, (2, 128, 56, 56))
+    f2 = _unit(rs, (2, 128, 56, 56))
+    dist, ind = pea.correspondence.dense_nn(f1, f2, 1)
+    assert ind.shape == (2, 1, 3136) and ind.min() >= 1 and ind.max() <= 3136
+    want, _ = cnative.nn_exact(f1[1].reshape(128, -1), f2[1].reshape(128, -1), 1, 1)
+    assert np.array_equal(ind[1], want)
+    xy = pea.correspondence.ind2coord(ind, 56)
+    assert np.array_equal(xy, okp.ind2coord(ind, 56))
+
+
+def test_nn_full_pair_64x64x128(pea):
+    rs = np.random.RandomState(2)
+    q = _unit(rs, (1, 128, 64, 64))
+    r = _unit(np.random.RandomState(3), (1, 128, 64, 64))
+    st = _nn_check(pea, q.reshape(1, 128, -1), r.reshape(1, 128, -1), 1)
+    assert st["exact_path_queries"] < 4096 // 8
+
+
+def test_nn_batch_and_bf16(pea):
+    rs = np.random.RandomState(8)
+    q = _unit(rs, (6, 128, 1024))
+    r = _unit(rs, (6, 128, 1024))
+    _nn_check(pea, q, r, 1)
+    _nn_check(pea, q, r, 1, bf16=True)
+    _nn_check(pea, q[:2], r[:2], 5, bf16=True)
+
+
+def test_nn_top5_c256(pea):
+    rs = np.random.RandomState(12)
+    _nn_check(pea, _unit(rs, (1, 256, 2048)), _unit(rs, (1, 256, 4096)), 5)
+
+
+def test_nn_full_size_properties(pea):
+    """BASELINE sizes the oracle cannot score in seconds: size-independent properties."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    r = torch.randn(8, 128, 4096, device="cuda", generator=g)
+    r = r / r.norm(dim=1, keepdim=True)
+    perm = torch.stack([torch.randperm(4096, device="cuda", generator=g) for _ in range(8)])
+    q = torch.gather(r, 2, perm[:, None, :].expand(-1, 128, -1)).contiguous()   # queries = permuted refs
+    dist, ind = pea.correspondence.dense_nn(q, r, 1, index_base=0)
+    assert torch.equal(ind[:, 0, :].long(), perm)            # every query finds itself
+    assert float(dist.abs().max()) <= 1e-5
+    d5, i5 = pea.correspondence.dense_nn(q, r, 5, index_base=0)
+    assert torch.equal(i5[:, 0, :].long(), perm)
+    assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())       # sorted ascending
+
+
+# ---------------------------------------------------------------- correlation maps
+@pytest.mark.parametrize("tag", ["b1k1", "b2k10", "b3k14"])
+def test_corr_eccv_golden(pea, golden_correlation, tag):
+    z = golden_correlation
+    f1 = z[f"{tag}_f1"].astype(np.float32)
+    f2 = z[f"{tag}_f2"].astype(np.float32)
+    layer = pea.correspondence.CorrelationMapLayer()
+    got = layer.forward(f1, f2, z[f"{tag}_knn"])
+    want = z[f"{tag}_out"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-7)       # 1e-4 relative (float32 bar)
+    with pytest.raises(IndexError):
+        layer.forward(f1, f2, np.array([[28, 0]]))
+
+
+def test_resize_and_l2norm(pea, golden_correlation):
+    z = golden_correlation
+    got = pea.correspondence.resize_bilinear(z["resize_in"], (28, 28))
+    assert np.allclose(got, z["resize_out"], rtol=1e-5, atol=1e-6)
+    x = np.random.RandomState(1).randn(3, 128, 56, 56).astype(np.float32)
+    assert np.allclose(pea.correspondence.l2norm(x), ocorr.l2norm(x), rtol=1e-6, atol=1e-7)
+
+
+def test_corr_acmm(pea, golden_correlation):
+    z = golden_correlation
+    rs = np.random.RandomState(2)
+    f1 = z["b2k10_f1"].astype(np.float32)
+    f2 = z["b2k10_f2"].astype(np.float32)
+    mask = (rs.rand(2, 1, 56, 56) > 0.4).astype(np.float32)
+    got = pea.correspondence.correlation_map_acmm(f1, f2, mask)
+    want = ocorr.correlation_map_acmm(f1, f2, mask)
+    assert got.shape == (2, 784, 28, 28)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-6)
+    # an all-zero column normalises to NaN in the reference (no epsilon): reproduce it
+    f2z = f2.copy()
+    f2z[:, :, :4, :4] = 0
+    got = pea.correspondence.correlation_map_acmm(f1, f2z, np.ones_like(mask))
+    assert np.isnan(got[:, :, 0, 0]).all() and np.isfinite(got[:, :, 20, 20]).all()
+
+
+def test_dense_keypoints(pea, golden_geometry, golden_disparity):
+    anchors = golden_geometry["g2_anchor_chair"]
+    depth = golden_disparity["rb_chair_depth"]
+    params = [120.0, 10.0, 0.0, 2.2]
+    crop = [60, 480, 250, 720]
+    got = pea.dense_pointset.dense_keypoints_for_renders(anchors, "chair", [params], depth, [crop])
+    want = okp.make_dense_keypoints_core(anchors, "chair", params, depth, crop)
+    assert got.shape == (1, 2, 130) and np.array_equal(got[0], want)
+
+
+def test_errors_are_loud(pea):
+    import torch
+    from pose_estimation_amd import _abi
+    with pytest.raises(_abi.IspaError):
+        _abi.check(_abi.lib.ispa_nn_topk(None, None, 0, 1, 8, 16, 16, 1, 1, None, None, None, 0, None, None))
+    q = torch.zeros(1, 8, 16, device="cuda")
+    ws = torch.empty(256, dtype=torch.uint8, device="cuda")
+    rc = _abi.lib.ispa_nn_topk(q.data_ptr(), q.data_ptr(), 0, 1, 8, 16, 16, 1, 1, q.data_ptr(), q.data_ptr(),
+                               ws.data_ptr(), 16, None, None)
+    assert rc == -3 and b"workspace" in _abi.lib.ispa_last_error()

@@ -1,0 +1,62 @@
+"""CPU: shard arithmetic and the result all-gather on a 2-rank gloo group."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _load_sharding():
+    # the package's __init__ loads the HIP library; sharding itself is pure torch
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ispa_sharding", os.path.join(here, "pose_estimation_amd", "sharding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_shard_range_covers_everything():
+    sh = _load_sharding()
+    for total in (0, 1, 7, 8, 4096, 3600):
+        for world in (1, 2, 3, 8):
+            blocks = [sh.shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert sh.shard_range(3600, 3, 8) == (1350, 1800)          # 450 poses per GPU
+    with pytest.raises(ValueError):
+        sh.shard_range(8, 8, 8)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = _load_sharding()
+    lo, hi = sh.shard_range(total, rank, world)
+    full = torch.arange(total * 3, dtype=torch.int32).reshape(total, 3)
+    got = sh.allgather_results(full[lo:hi].clone(), total)
+    ok = torch.equal(got, full)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_allgather_two_ranks_gloo(total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
