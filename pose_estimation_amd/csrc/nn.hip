@@ -12,6 +12,8 @@
 //                 the rounding bound of the filter is final, the others are queued
 //   4. exact      float64 re-scoring of every reference for the queued queries, in the channel
 //                 order the CPU oracle uses, so the index order is exact under all inputs
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -24,13 +26,24 @@ constexpr int kKC = 32;        // channels per LDS stage
 constexpr int kThreads = 256;  // 4 waves: 2 (reference halves) x 2 (query halves)
 constexpr int kSubStreams = 4; // partial result streams per (tile, split): wave-row x lane-half
 constexpr int kMaxK = 8;
-constexpr float kNegInf = -__builtin_inff();
+// Score of a masked (out-of-range) reference and of an empty list slot: a huge finite negative, so
+// that it survives the mantissa tagging below; anything under kAbsent counts as "no entry".
+constexpr float kNegInf = -3.0e38f;
+constexpr float kAbsent = -1.0e38f;
 
 // Optional timing of the filter kernel (the dominant launch) with HIP events on the caller's stream.
 struct FilterTiming {
     int capacity = 0, used = 0;
     hipEvent_t *start = nullptr, *stop = nullptr;
 } g_timing;
+
+// Blocks b and b+8 share an XCD (and its L2).  Renumber so that each XCD walks a contiguous range
+// of logical ids: the query tiles of one image pair, which all stream the same reference map, then
+// run on one L2.  Bijective for any grid size; a pure speed choice.
+__device__ __forceinline__ int xcd_order(int bid, int nblocks) {
+    const int q = nblocks >> 3, rem = nblocks & 7, x = bid & 7;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (bid >> 3);
+}
 
 __device__ __forceinline__ float load_as_float(const float *p) { return *p; }
 __device__ __forceinline__ float load_as_float(const uint16_t *p) {
@@ -42,21 +55,23 @@ __device__ __forceinline__ float load_as_float(const uint16_t *p) {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, int C, int64_t n,
-                                                       float *__restrict__ nh, int *__restrict__ maxbits) {
+                                                       float *__restrict__ nh, double *__restrict__ sq64,
+                                                       int *__restrict__ maxbits) {
     const int b = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
+    double s = 0.0;
     if (j < n) {
         const T *col = x + (int64_t)b * C * n + j;
-        for (int c = 0; c < C; ++c) {
-            const float v = load_as_float(col + (int64_t)c * n);
-            s = fmaf(v, v, s);
+        for (int c = 0; c < C; ++c) {          // channel order of the exact pass and of the oracle
+            const double v = (double)load_as_float(col + (int64_t)c * n);
+            s = fma(v, v, s);
         }
-        nh[(int64_t)b * n + j] = -0.5f * s;
+        nh[(int64_t)b * n + j] = (float)(-0.5 * s);
+        sq64[(int64_t)b * n + j] = s;
     }
     if (maxbits) {
-        // non-negative floats order like their bit patterns
-        float m = s;
+        // non-negative floats order like their bit patterns; round up so the bound stays a bound
+        float m = __double2float_ru(s);
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_int(m));
     }
@@ -65,18 +80,28 @@ __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, 
 // ---------------------------------------------------------------------------------------------
 // 2. filter pass, float32 MFMA (v_mfma_f32_32x32x2_f32: exact float32 fma chain over channels)
 // ---------------------------------------------------------------------------------------------
+// Running top list of one query stream.  Interface shared by both implementations:
+//   begin_half(id)  start of a half-step (32 reference rows = 16 accumulator registers per lane)
+//   push(x, reg)    score of accumulator register `reg` (compile-time after unrolling)
+//   end_half()
+//   value(s), code(s)  s-th best score and its code = half_step_id * 16 + reg (-1: none)
 template <int K>
-struct TopList {            // K+1 best scores (descending) and the codes of the first K... all K+1
+struct TopList {            // K+1 best scores, descending, each with its code
     float v[K + 1];
     int c[K + 1];
+    int base;
     __device__ __forceinline__ void init() {
 #pragma unroll
         for (int s = 0; s <= K; ++s) {
             v[s] = kNegInf;
             c[s] = -1;
         }
+        base = 0;
     }
-    __device__ __forceinline__ void push(float x, int code) {
+    __device__ __forceinline__ void begin_half(int id) { base = id * 16; }
+    __device__ __forceinline__ void end_half() {}
+    __device__ __forceinline__ void push(float x, int reg) {
+        const int code = base + reg;
         if (K == 1) {
             v[1] = __builtin_amdgcn_fmed3f(v[0], v[1], x);
             const bool better = x > v[0];
@@ -99,6 +124,49 @@ struct TopList {            // K+1 best scores (descending) and the codes of the
             }
         }
     }
+    __device__ __forceinline__ float value(int s) const { return v[s]; }
+    __device__ __forceinline__ int code(int s) const { return v[s] > kAbsent ? c[s] : -1; }
+};
+
+// Top-1 (plus the runner-up's score) at three vector instructions per score: the accumulator
+// register number replaces the 4 low mantissa bits of the score (a perturbation below 2^-19
+// relative, accounted for in the margin test), so the best score carries its own position and
+// v_max / v_med3 do all the work; the half-step that produced it is tracked once per 16 scores.
+struct TagTop1 {
+    float a, b, a_before, pinf;
+    int half, cur;
+    __device__ __forceinline__ void init() {
+        a = b = kNegInf;
+        half = -1;
+        cur = 0;
+        // +inf in a register the optimiser cannot see through: med3(a, t, +inf) then stays ONE
+        // v_med3_f32 instead of a canonicalising v_max pair
+        pinf = __builtin_inff();
+        asm volatile("" : "+v"(pinf));
+    }
+    __device__ __forceinline__ void begin_half(int id) {
+        cur = id;
+        a_before = a;
+    }
+    __device__ __forceinline__ void push(float x, int reg) {
+        const float t = __uint_as_float((__float_as_uint(x) & 0xfffffff0u) | (unsigned)reg);
+        b = __builtin_amdgcn_fmed3f(a, b, t);
+        a = __builtin_amdgcn_fmed3f(a, t, pinf);               // max(a, t) as one instruction
+    }
+    __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
+    __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
+    __device__ __forceinline__ int code(int s) const {
+        return (s == 0 && a > kAbsent) ? half * 16 + (int)(__float_as_uint(a) & 15u) : -1;
+    }
+};
+
+template <int K, bool TAGGED>
+struct ListFor {
+    typedef TopList<K> type;
+};
+template <>
+struct ListFor<1, true> {
+    typedef TagTop1 type;
 };
 
 // Guarded tile loader: rows = channels [c0, c0+kKC), columns = [n0, n0+128) of x (C, n) -> LDS.
@@ -147,7 +215,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
     __shared__ float Nh[kTR];
 
     // block -> (pair, split, query tile)
-    int bid = blockIdx.x;
+    int bid = xcd_order(blockIdx.x, gridDim.x);
     const int qt = bid % n_qtiles;
     bid /= n_qtiles;
     const int split = bid % nsplit;
@@ -207,9 +275,12 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri)
+            for (int ri = 0; ri < 2; ++ri) {
+                best[qi].begin_half(chunk * 2 + ri);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) best[qi].push(acc[ri][qi][reg], chunk * 32 + ri * 16 + reg);
+                for (int reg = 0; reg < 16; ++reg) best[qi].push(acc[ri][qi][reg], reg);
+                best[qi].end_half();
+            }
     }
 
     // one partial stream per (split, wr, h); finalize merges them
@@ -221,14 +292,246 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
         if (qcol >= nq) continue;
 #pragma unroll
         for (int s = 0; s <= K; ++s) {
-            const int code = best[qi].c[s];
+            const int code = best[qi].code(s);
             int ref = -1;
             if (code >= 0) {
                 const int reg = code & 15, ri = (code >> 4) & 1;
                 ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
             }
             const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
-            part_val[o] = best[qi].v[s];
+            part_val[o] = best[qi].value(s);
+            part_idx[o] = ref;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2b. filter pass, bfloat16 MFMA (v_mfma_f32_32x32x16_bf16, float32 accumulation)
+//
+// One 512-thread block = 256 queries x (a split of) all references.  The 8 waves form a 4 (query
+// groups of 64) x 2 (reference halves of 64) grid.  Both operands are channel-major in memory
+// (C rows of cells), which is the TRANSPOSE of what the MFMA fragments want (8 consecutive channels
+// per lane), so tiles are copied to LDS as they are and read back with ds_read_b64_tr_b16.  The
+// query fragments of a wave are read once and stay in registers (C/2 VGPRs) for the whole kernel;
+// reference chunks of 128 cells stream through a double-buffered LDS image, prefetched through
+// registers one chunk ahead.  Rows are padded by 64 bytes so that the four rows a transposed read
+// touches fall on four different bank quarters.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBQ = 256;             // queries per block
+constexpr int kBThreads = 512;
+constexpr int kRStride = 256 + 64;   // bytes per LDS row of 128 bf16 reference cells
+constexpr int kQStride = 512 + 64;   // bytes per LDS row of 256 bf16 query cells
+
+__device__ __forceinline__ bf16x8 tr_frag(const char *lds_row0_col, int stride) {
+    // rows k..k+3 then k+4..k+7 of the 16-column block this lane group addresses
+    typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds_row0_col));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds_row0_col + 4 * stride));
+    return u.v;
+}
+
+template <int KS, int K>
+__global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
+    const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
+    int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
+    int *__restrict__ part_idx) {
+    constexpr int C = 16 * KS;
+    constexpr int kRBuf = C * kRStride;                 // one reference chunk image
+    constexpr int kSeg = KS / 2;                        // 16-byte segments per thread per chunk
+    static_assert(KS % 2 == 0 && KS <= 8, "C must be a multiple of 32, at most 128");
+    static_assert(C * kQStride <= 2 * kRBuf, "query staging must fit in the reference buffers");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *rbuf = lds;                                   // 2 * kRBuf
+    float *nhbuf = reinterpret_cast<float *>(lds + 2 * kRBuf);   // 2 * 128 floats
+
+    int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int qt = bid % n_qtiles;
+    bid /= n_qtiles;
+    const int split = bid % nsplit;
+    const int b = bid / nsplit;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wq = wave & 3, wr = wave >> 2;
+    const int l31 = lane & 31, h = lane >> 5;
+    // transposed-read addressing: 16-lane group g covers columns 16*(g&1).., channels 8*(g>>1)..
+    const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int tr_row = 8 * h + ((lane & 15) >> 2);
+
+    const uint16_t *qb = q + (int64_t)b * C * nq;
+    const uint16_t *rb = r + (int64_t)b * C * nr;
+    const float *nhb = rnh + (int64_t)b * nr;
+    const int64_t q0 = (int64_t)qt * kBQ;
+    const int64_t rbeg = (int64_t)split * refs_per_split;
+    const int64_t rend = min(rbeg + refs_per_split, nr);
+    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+
+    // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
+    for (int e = 0; e < KS; ++e) {                       // C rows x 32 segments of 8 queries
+        const int seg = tid + kBThreads * e;
+        const int row = seg >> 5, col = (seg & 31) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)row * nq + q0 + col);
+        *reinterpret_cast<uint4 *>(lds + row * kQStride + col * 2) = v;
+    }
+    // first reference chunk: global -> registers while the query tile settles
+    // Branch-free so that the chunk loop is one basic block: out-of-range lanes load from a valid
+    // address (the row start) and the value is replaced by zero / -inf afterwards.
+    uint4 pre[kSeg];
+    float pre_nh = 0.f;
+    unsigned pre_ok = 0;         // bit e: segment e in range, bit 31: the norm entry in range
+    auto prefetch = [&](int64_t r0) {
+        pre_ok = 0;
+#pragma unroll
+        for (int e = 0; e < kSeg; ++e) {                 // C rows x 16 segments of 8 references
+            const int seg = tid + kBThreads * e;
+            const int row = seg >> 4, col = (seg & 15) * 8;
+            const bool ok = r0 + col < rend;
+            pre_ok |= ok ? 1u << e : 0u;
+            pre[e] = *reinterpret_cast<const uint4 *>(rb + (int64_t)row * nr + (ok ? r0 + col : 0));
+        }
+        const bool okn = r0 + (tid & (kTR - 1)) < rend;
+        pre_ok |= okn ? 0x80000000u : 0u;
+        pre_nh = nhb[okn ? r0 + (tid & (kTR - 1)) : 0];
+    };
+    // the masking is applied here, long after the loads were issued, so that nothing waits on them early
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < kSeg; ++e) {
+            const int seg = tid + kBThreads * e;
+            const int row = seg >> 4, col = (seg & 15) * 8;
+            const bool ok = (pre_ok >> e) & 1u;
+            uint4 v;
+            v.x = ok ? pre[e].x : 0u;
+            v.y = ok ? pre[e].y : 0u;
+            v.z = ok ? pre[e].z : 0u;
+            v.w = ok ? pre[e].w : 0u;
+            *reinterpret_cast<uint4 *>(rbuf + buf * kRBuf + row * kRStride + col * 2) = v;
+        }
+        nhbuf[buf * kTR + (tid & (kTR - 1))] = (pre_ok >> 31) ? pre_nh : kNegInf;   // four waves write the same values
+    };
+    if (nchunks > 0) prefetch(rbeg);
+    __syncthreads();
+    bf16x8 bq[2][KS];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bq[qi][ks] = tr_frag(lds + (ks * 16 + tr_row) * kQStride + (wq * 64 + qi * 32 + tr_col) * 2, kQStride);
+    __syncthreads();                                     // query image no longer needed
+    if (nchunks > 0) commit(0);
+    __syncthreads();
+
+    typename ListFor<K, true>::type best[2];
+    best[0].init();
+    best[1].init();
+
+    // Each chunk is two half-steps (reference rows 0-31 and 32-63 of this wave's 64).  The MFMAs of
+    // one half-step are interleaved, in a pinned program order, with the top-list update of the
+    // previous half-step's accumulators, so the matrix pipe and the vector ALU work at the same
+    // time; the transposed LDS reads run one k-step ahead of their MFMAs.
+    f32x16 acc_a[2], acc_b[2];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc_b[0][reg] = acc_b[1][reg] = kNegInf;   // nothing pending yet
+    // opaque to the optimiser: otherwise it peels the first iteration to fold these constants and
+    // the pinned MFMA / vector interleave of the steady-state loop is lost
+    asm volatile("" : "+v"(acc_b[0]), "+v"(acc_b[1]));
+
+    auto load_init = [&](const float *nh, int ri) {
+        f32x16 v;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4 *>(nh + wr * 64 + ri * 32 + 8 * g + 4 * h);
+            v[4 * g + 0] = t.x;
+            v[4 * g + 1] = t.y;
+            v[4 * g + 2] = t.z;
+            v[4 * g + 3] = t.w;
+        }
+        return v;
+    };
+    auto frag = [&](const char *rimg, int ri, int ks) {
+        return tr_frag(rimg + (ks * 16 + tr_row) * kRStride + (wr * 64 + ri * 32 + tr_col) * 2, kRStride);
+    };
+    // MFMAs of half-step `ri` into `now`, top-list update of `prev` (half-step id prev_half).
+    // The transposed LDS reads run two k-steps ahead: a0 / a1 hold the fragments of k-steps 0 and 1
+    // on entry, and those of the next half-step (`next_img`, `next_ri`; has_next = false_type when
+    // its image is not in LDS yet) on exit.
+    auto half_step = [&](auto has_next, const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 &a0,
+                         bf16x8 &a1, const f32x16 &init, f32x16 (&now)[2], const f32x16 (&prev)[2],
+                         int prev_half) {
+        best[0].begin_half(prev_half);
+        best[1].begin_half(prev_half);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a2 = a1;
+            if (ks + 2 < KS)
+                a2 = frag(rimg, ri, ks + 2);
+            else if (decltype(has_next)::value)
+                a2 = frag(next_img, next_ri, ks + 2 - KS);
+            now[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][ks], ks ? now[0] : init, 0, 0, 0);
+#pragma unroll
+            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) best[0].push(prev[0][reg], reg);
+            now[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][ks], ks ? now[1] : init, 0, 0, 0);
+#pragma unroll
+            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) best[1].push(prev[1][reg], reg);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1;
+            a1 = a2;
+        }
+        best[0].end_half();
+        best[1].end_half();
+    };
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        // the last iteration re-fetches its own chunk into the idle buffer: harmless, and it keeps
+        // the loop body free of branches
+        prefetch(rbeg + (int64_t)(chunk + 1 < nchunks ? chunk + 1 : chunk) * kTR);
+        const char *rimg = rbuf + buf * kRBuf;
+        const float *nh = nhbuf + buf * kTR;
+        bf16x8 a0 = frag(rimg, 0, 0), a1 = frag(rimg, 0, 1);
+        const f32x16 init0 = load_init(nh, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(std::true_type(), rimg, 0, rimg, 1, a0, a1, init0, acc_a, acc_b, chunk * 2 - 1);
+        const f32x16 init1 = load_init(nh, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(std::false_type(), rimg, 1, rimg, 0, a0, a1, init1, acc_b, acc_a, chunk * 2);
+        commit(buf ^ 1);      // the loads were issued a whole chunk ago
+        __syncthreads();
+    }
+    if (nchunks > 0) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            best[qi].begin_half(nchunks * 2 - 1);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) best[qi].push(acc_b[qi][reg], reg);
+            best[qi].end_half();
+        }
+    }
+
+    const int nparts = nsplit * kSubStreams;
+    const int part = split * kSubStreams + wr * 2 + h;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
+        if (qcol >= nq) continue;
+#pragma unroll
+        for (int s = 0; s <= K; ++s) {
+            const int code = best[qi].code(s);
+            int ref = -1;
+            if (code >= 0) {
+                const int reg = code & 15, ri = (code >> 4) & 1;
+                ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+            }
+            const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
+            part_val[o] = best[qi].value(s);
             part_idx[o] = ref;
         }
     }
@@ -243,7 +546,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ qnh,
                                                           const int *__restrict__ rmaxbits, int C, int64_t nq,
                                                           int64_t nr, int k_out, int index_base,
-                                                          float err_factor, float *__restrict__ dist,
+                                                          float err_rel, float *__restrict__ dist,
                                                           int *__restrict__ idx, int *__restrict__ amb_count,
                                                           int *__restrict__ amb_list) {
     const int b = blockIdx.y;
@@ -264,7 +567,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             const int64_t o = (((int64_t)b * nparts + p) * (K + 1) + s) * nq + i;
             const float x = part_val[o];
             const unsigned code = (unsigned)part_idx[o];   // -1 sorts after every real index
-            if (!(x > kNegInf) && x == x) break;            // absent (NaN falls through)
+            if (!(x > kAbsent) && x == x) break;            // absent (NaN falls through)
             if (x > v[K] || (x == v[K] && code < (unsigned)c[K]) || x != x) {
                 v[K] = x;
                 c[K] = (int)code;
@@ -283,28 +586,30 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                 }
             }
         }
-    // rounding bound of one filter score: (C+2) roundings of magnitude <= u * (|q||r| + |r|^2/2)
+    // two filter scores are ordered for certain when they differ by more than
+    // err_rel * (|q| max|r| + max|r|^2 / 2); err_rel comes from the filter kernel's rounding model
     const float qq = -2.f * qnh[(int64_t)b * nq + i];
     const float rmax2 = __int_as_float(rmaxbits[b]);
     const float scale = sqrtf(qq) * sqrtf(rmax2) + 0.5f * rmax2;
-    const float delta = err_factor * (float)(C + 2) * 5.9604645e-8f * scale;
+    const float delta = err_rel * scale;
     bool sure = true;
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         if (s >= k_out) break;
-        if (!(v[s] > kNegInf)) {                   // fewer references than k (or NaN: exact pass)
+        if (!(v[s] > kAbsent)) {                   // fewer references than k (or NaN: exact pass)
             if (v[s] != v[s]) sure = false;
             break;
         }
         if (c[s] < 0) sure = false;                // cannot happen for distinct scores; be safe
         if (v[s + 1] != v[s + 1]) sure = false;
-        if (v[s + 1] > kNegInf && !(v[s] - v[s + 1] > delta)) sure = false;
+        if (v[s + 1] > kAbsent && !(v[s] - v[s + 1] > delta)) sure = false;
     }
     if (sure) {
         for (int s = 0; s < k_out; ++s) {
             const int64_t o = ((int64_t)b * k_out + s) * nq + i;
-            idx[o] = c[s] >= 0 ? c[s] + index_base : -1;
-            dist[o] = c[s] >= 0 ? qq - 2.f * v[s] : __builtin_inff();
+            const bool have = v[s] > kAbsent && c[s] >= 0;
+            idx[o] = have ? c[s] + index_base : -1;
+            dist[o] = have ? qq - 2.f * v[s] : __builtin_inff();
         }
     } else {
         const int slot = atomicAdd(amb_count, 1);
@@ -315,23 +620,27 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------
 // 4. exact float64 pass for the queued queries
 // ---------------------------------------------------------------------------------------------
-struct DKey {
-    double d;
-    int j;
-};
 __device__ __forceinline__ bool key_less(double d0, int j0, double d1, int j1) {
     return d0 < d1 || (d0 == d1 && j0 < j1);
 }
 
+// One block per queued query.  d2(j) = (qq + rr_j) - 2 dot_j with dot accumulated over channels in
+// increasing order in float64 (every product of two float32 values is exact in float64); qq and
+// rr come from the norms kernel, accumulated the same way.  Four references per thread are in
+// flight at a time so that the dependent fma chains overlap.
 template <typename T>
-__global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, const T *__restrict__ r, int C,
-                                                       int64_t nq, int64_t nr, int k_out, int index_base,
+__global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, const T *__restrict__ r,
+                                                       const double *__restrict__ qq64,
+                                                       const double *__restrict__ rr64, int C, int64_t nq,
+                                                       int64_t nr, int k_out, int index_base,
                                                        const int *__restrict__ amb_count,
                                                        const int *__restrict__ amb_list,
                                                        float *__restrict__ dist, int *__restrict__ idx) {
-    __shared__ double sd[256];
-    __shared__ int sj[256];
-    __shared__ int sown[256];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *qs = reinterpret_cast<double *>(smem);                 // C doubles
+    double *sd = qs + C;                                           // 256 doubles
+    int *sj = reinterpret_cast<int *>(sd + 256);                   // 256 ints
+    int *sown = sj + 256;                                          // 256 ints
     const int count = *amb_count;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int64_t flat = amb_list[w];
@@ -339,44 +648,57 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
         const int64_t i = flat % nq;
         const T *qcol = q + (int64_t)b * C * nq + i;
         const T *rb = r + (int64_t)b * C * nr;
-        double qq = 0.0;
-        for (int c = 0; c < C; ++c) {
-            const double v = (double)load_as_float(qcol + (int64_t)c * nq);
-            qq = fma(v, v, qq);
-        }
-        // thread-local top-k over its strided share of the references, ascending (d, j)
+        const double *rrb = rr64 + (int64_t)b * nr;
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) qs[c] = (double)load_as_float(qcol + (int64_t)c * nq);
+        __syncthreads();
+        const double qq = qq64[flat];
         double bd[kMaxK];
         int bj[kMaxK];
+#pragma unroll
         for (int s = 0; s < kMaxK; ++s) {
             bd[s] = __builtin_inf();
             bj[s] = 0x7fffffff;
         }
-        for (int64_t j = threadIdx.x; j < nr; j += 256) {
-            double dot = 0.0, rr = 0.0;
-            for (int c = 0; c < C; ++c) {
-                const double qv = (double)load_as_float(qcol + (int64_t)c * nq);
-                const double rv = (double)load_as_float(rb + (int64_t)c * nr + j);
-                dot = fma(qv, rv, dot);
-                rr = fma(rv, rv, rr);
+        for (int64_t j0 = threadIdx.x; j0 < nr; j0 += 1024) {
+            double dot[4] = {0.0, 0.0, 0.0, 0.0};
+            const T *rp[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                in[u] = j0 + 256 * u < nr;
+                rp[u] = rb + (in[u] ? j0 + 256 * u : j0);
             }
-            const double d = (qq + rr) - 2.0 * dot;
-            if (key_less(d, (int)j, bd[k_out - 1], bj[k_out - 1])) {
-                int pos = k_out - 1;
-                while (pos > 0 && key_less(d, (int)j, bd[pos - 1], bj[pos - 1])) {
-                    bd[pos] = bd[pos - 1];
-                    bj[pos] = bj[pos - 1];
-                    --pos;
+            for (int c = 0; c < C; ++c) {
+                const double qv = qs[c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[u] = fma(qv, (double)load_as_float(rp[u] + (int64_t)c * nr), dot[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!in[u]) continue;
+                const int j = (int)(j0 + 256 * u);
+                const double d = (qq + rrb[j]) - 2.0 * dot[u];
+                // insert into the thread-local ascending list (static indexing keeps it in registers)
+                double cd = d;
+                int cj = j;
+#pragma unroll
+                for (int s = 0; s < kMaxK; ++s) {
+                    const bool lt = key_less(cd, cj, bd[s], bj[s]);
+                    const double td = lt ? bd[s] : cd;
+                    const int tj = lt ? bj[s] : cj;
+                    bd[s] = lt ? cd : bd[s];
+                    bj[s] = lt ? cj : bj[s];
+                    cd = td;
+                    cj = tj;
                 }
-                bd[pos] = d;
-                bj[pos] = (int)j;
             }
         }
         // k_out rounds of block-wide lexicographic minimum over the thread-local heads
-        int head = 0;
         for (int s = 0; s < k_out; ++s) {
             __syncthreads();
-            sd[threadIdx.x] = head < k_out ? bd[head] : __builtin_inf();
-            sj[threadIdx.x] = head < k_out ? bj[head] : 0x7fffffff;
+            sd[threadIdx.x] = bd[0];
+            sj[threadIdx.x] = bj[0];
             sown[threadIdx.x] = threadIdx.x;
             __syncthreads();
             for (int off = 128; off > 0; off >>= 1) {
@@ -390,8 +712,15 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                 }
                 __syncthreads();
             }
-            const int owner = sown[0];
-            if (threadIdx.x == owner) ++head;
+            if ((int)threadIdx.x == sown[0]) {      // pop the winner from its owner's list
+#pragma unroll
+                for (int t = 0; t + 1 < kMaxK; ++t) {
+                    bd[t] = bd[t + 1];
+                    bj[t] = bj[t + 1];
+                }
+                bd[kMaxK - 1] = __builtin_inf();
+                bj[kMaxK - 1] = 0x7fffffff;
+            }
             if (threadIdx.x == 0) {
                 const int64_t o = ((int64_t)b * k_out + s) * nq + i;
                 const bool have = sj[0] != 0x7fffffff;
@@ -399,7 +728,6 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                 dist[o] = have ? (float)sd[0] : __builtin_inff();
             }
         }
-        __syncthreads();
     }
 }
 
@@ -407,50 +735,83 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
 // host side
 // ---------------------------------------------------------------------------------------------
 struct Plan {
+    bool bf16_mfma;          // native bf16 MFMA filter (else the float32 MFMA filter)
+    int tq;                  // queries per block of the chosen filter
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
-    size_t off_qnh, off_rnh, off_rmax, off_count, off_list, off_pval, off_pidx, total;
+    size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_list, off_pval, off_pidx, total;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-Plan make_plan(int B, int64_t nq, int64_t nr, int k) {
+Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
-    p.n_qtiles = (int)((nq + kTQ - 1) / kTQ);
+    p.bf16_mfma = dtype == ISPA_BF16 && C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
+    p.tq = p.bf16_mfma ? kBQ : kTQ;
+    p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
     p.ktemplate = k == 1 ? 1 : (k <= 5 ? 5 : kMaxK);
     const int64_t chunks = (nr + kTR - 1) / kTR;
-    // aim for >= 1024 workgroups (4 per CU) without going below 2 chunks per split
+    // enough workgroups to fill 256 CUs a few times over, without going below 2 chunks per split
+    const int64_t want = p.bf16_mfma ? 512 : 1024;
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
-    while (base * nsplit < 1024 && chunks / (nsplit * 2) >= 2) nsplit *= 2;
-    int64_t cps = (chunks + nsplit - 1) / nsplit;
+    while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
+    const int64_t cps = (chunks + nsplit - 1) / nsplit;
     p.refs_per_split = cps * kTR;
     p.nsplit = (int)((chunks + cps - 1) / cps);
     p.nparts = p.nsplit * kSubStreams;
     size_t off = 0;
-    p.off_qnh = off;
-    off = align_up(off + sizeof(float) * B * nq, 256);
-    p.off_rnh = off;
-    off = align_up(off + sizeof(float) * B * nr, 256);
-    p.off_rmax = off;
-    off = align_up(off + sizeof(int) * B, 256);
-    p.off_count = off;
-    off = align_up(off + 16, 256);
-    p.off_list = off;
-    off = align_up(off + sizeof(int) * B * nq, 256);
-    p.off_pval = off;
-    off = align_up(off + sizeof(float) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq, 256);
-    p.off_pidx = off;
-    off = align_up(off + sizeof(int) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq, 256);
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    p.off_qnh = take(sizeof(float) * B * nq);
+    p.off_rnh = take(sizeof(float) * B * nr);
+    p.off_q64 = take(sizeof(double) * B * nq);
+    p.off_r64 = take(sizeof(double) * B * nr);
+    p.off_rmax = take(sizeof(int) * B);
+    p.off_count = take(16);
+    p.off_list = take(sizeof(int) * B * nq);
+    p.off_pval = take(sizeof(float) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
+    p.off_pidx = take(sizeof(int) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.total = off;
     return p;
 }
 
+template <int KS, int KT>
+int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
+                int64_t nr, const Plan &p, float *pval, int *pidx) {
+    constexpr int lds_bytes = 2 * 16 * KS * kRStride + 2 * kTR * (int)sizeof(float);
+    static bool configured = false;       // per instantiation
+    if (!configured) {
+        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
+    return ISPA_OK;
+}
+
+template <int KT>
+int launch_bf16_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh,
+                   int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx) {
+    switch (ks) {
+        case 2: return launch_bf16<2, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 4: return launch_bf16<4, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 6: return launch_bf16<6, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        default: return launch_bf16<8, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+    }
+}
+
 template <typename T>
 int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int index_base, float *dist,
-        int32_t *idx, char *ws, const Plan &p, int32_t *stats, hipStream_t s, float err_factor) {
+        int32_t *idx, char *ws, const Plan &p, int32_t *stats, hipStream_t s) {
     float *qnh = (float *)(ws + p.off_qnh);
     float *rnh = (float *)(ws + p.off_rnh);
+    double *q64 = (double *)(ws + p.off_q64);
+    double *r64 = (double *)(ws + p.off_r64);
     int *rmax = (int *)(ws + p.off_rmax);
     int *count = (int *)(ws + p.off_count);
     int *list = (int *)(ws + p.off_list);
@@ -460,40 +821,67 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     // rmax and count are adjacent blocks; zero both (sizes are multiples of 256 bytes)
     ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
     hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, q, C, nq, qnh,
-                       (int *)nullptr);
+                       q64, (int *)nullptr);
     hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr, rnh,
-                       rmax);
+                       r64, rmax);
     if (int rc = ispa::check_launch("nn_norms_kernel")) return rc;
 
-    const int elem = (int)sizeof(T);
-    const int vec = 16 / elem <= 4 ? 4 : 4;  // groups of 4 elements
-    const int vec_ok = (nq % vec == 0) && (nr % vec == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
-                       ((uintptr_t)r % (4 * elem) == 0);
     const int64_t nblocks = (int64_t)B * p.nsplit * p.n_qtiles;
     ISPA_REQUIRE(nblocks < (1ll << 31), "problem too large for one launch");
-    dim3 grid((unsigned)nblocks), block(kThreads);
+    const dim3 grid((unsigned)nblocks);
     const bool timed = g_timing.used < g_timing.capacity;
-#define ISPA_LAUNCH_FILTER(KT)                                                                              \
-    if (timed) (void)hipEventRecord(g_timing.start[g_timing.used], s);                                      \
-    hipLaunchKernelGGL((nn_filter_f32_kernel<T, KT>), grid, block, 0, s, q, r, rnh, C, nq, nr, p.n_qtiles,  \
-                       p.nsplit, p.refs_per_split, pval, pidx, vec_ok);                                     \
-    if (timed) (void)hipEventRecord(g_timing.stop[g_timing.used++], s);                                     \
-    hipLaunchKernelGGL((nn_finalize_kernel<KT>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, pval, \
-                       pidx, p.nparts, qnh, rmax, C, nq, nr, k, index_base, err_factor, dist, idx, count, list)
-    if (p.ktemplate == 1) {
-        ISPA_LAUNCH_FILTER(1);
-    } else if (p.ktemplate == 5) {
-        ISPA_LAUNCH_FILTER(5);
+    if (timed) (void)hipEventRecord(g_timing.start[g_timing.used], s);
+    float err_rel;
+    const float u = 5.9604645e-8f;   // 2^-24
+    if (p.bf16_mfma) {
+        // rounding model of v_mfma_f32_32x32x16_bf16: products of two bf16 are exact in float32; each
+        // instruction adds 16 of them to the accumulator with a total error of at most 4 units in
+        // the last place of the largest magnitude involved.  (C/16 + 1) such steps, two scores
+        // compared, 1.25 safety.  tests/test_gpu_parity.py measures the real error against this.
+        err_rel = 2.f * 1.25f * 4.f * (float)(C / 16 + 1) * 2.f * u;
+        if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
+        const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
+        int rc;
+        if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        if (rc) return rc;
     } else {
-        ISPA_LAUNCH_FILTER(kMaxK);
+        // v_mfma_f32_32x32x2_f32 is a k-ordered float32 fma chain: C+1 roundings of at most
+        // u * (|q||r| + |r|^2/2) each; two scores compared, 1.25 safety.
+        err_rel = 2.f * 1.25f * (float)(C + 2) * u;
+        const int elem = (int)sizeof(T);
+        const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
+                           ((uintptr_t)r % (4 * elem) == 0);
+        if (p.ktemplate == 1)
+            hipLaunchKernelGGL((nn_filter_f32_kernel<T, 1>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
+                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
+        else if (p.ktemplate == 5)
+            hipLaunchKernelGGL((nn_filter_f32_kernel<T, 5>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
+                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
+        else
+            hipLaunchKernelGGL((nn_filter_f32_kernel<T, kMaxK>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
+                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
     }
-#undef ISPA_LAUNCH_FILTER
-    if (int rc = ispa::check_launch("nn_filter/finalize")) return rc;
+    if (timed) (void)hipEventRecord(g_timing.stop[g_timing.used++], s);
+    if (int rc = ispa::check_launch("nn_filter")) return rc;
+
+    const dim3 fgrid(ispa::blocks_for(nq, 256), B);
+#define ISPA_FINALIZE(KT)                                                                                     \
+    hipLaunchKernelGGL((nn_finalize_kernel<KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
+                       nr, k, index_base, err_rel, dist, idx, count, list)
+    if (p.ktemplate == 1) ISPA_FINALIZE(1);
+    else if (p.ktemplate == 5) ISPA_FINALIZE(5);
+    else ISPA_FINALIZE(kMaxK);
+#undef ISPA_FINALIZE
+    if (int rc = ispa::check_launch("nn_finalize_kernel")) return rc;
 
     const int64_t total_q = (int64_t)B * nq;
-    const unsigned eblocks = (unsigned)(total_q < 2048 ? total_q : 2048);
-    hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), 0, s, q, r, C, nq, nr, k, index_base,
-                       count, list, dist, idx);
+    const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096);
+    const size_t esmem = (size_t)C * sizeof(double) + 256 * (sizeof(double) + 2 * sizeof(int));
+    ISPA_REQUIRE(esmem <= 64 * 1024, "too many channels (%d) for the exact pass", C);
+    hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr, k,
+                       index_base, count, list, dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
     if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;
@@ -502,9 +890,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 }  // namespace
 
 extern "C" size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k) {
-    (void)C;
-    if (B <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
-    return make_plan(B, nq, nr, k).total;
+    if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
+    // the larger of the two dtype plans, so that one workspace serves both
+    const size_t a = make_plan(ISPA_F32, B, C, nq, nr, k).total;
+    const size_t b = make_plan(ISPA_BF16, B, C, nq, nr, k).total;
+    return a > b ? a : b;
 }
 
 extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
@@ -518,17 +908,20 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
     ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31), "problem too large");
     ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
     ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16, "unknown dtype %d", dtype);
-    const Plan p = make_plan(B, nq, nr, k);
+    Plan p = make_plan(dtype, B, C, nq, nr, k);
+    if (p.bf16_mfma && (((uintptr_t)q | (uintptr_t)r) % 16 != 0)) {
+        p = make_plan(ISPA_F32, B, C, nq, nr, k);       // unaligned bf16 input: converting tile loader
+        p.bf16_mfma = false;
+    }
     if (workspace_bytes < p.total)
         return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, p.total);
     ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    // error factor: 2 scores compared, 1.25 safety on the float32 fma-chain bound
     if (dtype == ISPA_F32)
         return run((const float *)q, (const float *)r, B, C, nq, nr, k, index_base, dist, idx, (char *)workspace,
-                   p, stats, s, 2.5f);
+                   p, stats, s);
     return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, k, index_base, dist, idx,
-               (char *)workspace, p, stats, s, 2.5f);
+               (char *)workspace, p, stats, s);
 }
 
 extern "C" int ispa_timing_enable(int max_records) {

@@ -335,6 +335,37 @@ def test_nn_batch_and_bf16(pea):
     _nn_check(pea, q[:2], r[:2], 5, bf16=True)
 
 
+def test_nn_bf16_shapes_and_error_model(pea):
+    import torch
+    rs = np.random.RandomState(31)
+    # native bf16 MFMA path: C in {32,64,96,128}, cell counts multiples of 8 but not of the tile
+    for (b, c, nq, nr) in ((2, 64, 264, 520), (1, 32, 8, 136), (3, 96, 512, 384), (1, 128, 2048, 4096)):
+        _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), 1, bf16=True)
+    _nn_check(pea, _unit(rs, (2, 128, 520)), _unit(rs, (2, 128, 1032)), 5, bf16=True)
+    # shapes the native path does not take (converting loader + float32 MFMA)
+    _nn_check(pea, _unit(rs, (2, 48, 100)), _unit(rs, (2, 48, 333)), 1, bf16=True)
+    # the margin test relies on a rounding model of the bf16 MFMA: measure the real error of the
+    # filter scores (through the returned distances) on benign and on cancellation-heavy data
+    for scale_mix in (False, True):
+        q = _unit(rs, (2, 128, 1024))
+        r = _unit(rs, (2, 128, 2048))
+        if scale_mix:       # a few huge channels that cancel: partial sums far above the result
+            q[:, :4] *= 30.0
+            r[:, :4] *= 30.0
+            r[:, 1] = -r[:, 0] * (q[:, 0:1].mean() / max(abs(q[:, 1:2].mean()), 1e-3))
+        qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+        rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
+        dist, ind = pea.correspondence.dense_nn(qd, rd, 1)
+        qr, rr = cnative.round_bf16(q), cnative.round_bf16(r)
+        for i in range(2):
+            _, want_d = cnative.nn_exact(qr[i], rr[i], 1, 1)
+            qn = np.sqrt((qr[i].astype(np.float64) ** 2).sum(0))
+            rmax2 = (rr[i].astype(np.float64) ** 2).sum(0).max()
+            bound = 4.0 * 9 * 2 * 2.0 ** -24 * (qn * np.sqrt(rmax2) + 0.5 * rmax2)    # per score, no safety
+            err = np.abs(dist[i].cpu().numpy().astype(np.float64) - want_d)[0] / 2.0
+            assert np.all(err <= 0.25 * bound + 2.0 ** -22 * (qn ** 2)), float((err / bound).max())
+
+
 def test_nn_top5_c256(pea):
     rs = np.random.RandomState(12)
     _nn_check(pea, _unit(rs, (1, 256, 2048)), _unit(rs, (1, 256, 4096)), 5)
