@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libispa_hip.so")
+# ISPA_HIP_LIBRARY points at another build of the same library (development builds)
+LIB_PATH = os.environ.get("ISPA_HIP_LIBRARY") or os.path.join(_HERE, "libispa_hip.so")
 
 ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1

@@ -62,7 +62,15 @@ __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, 
     double s = 0.0;
     if (j < n) {
         const T *col = x + (int64_t)b * C * n + j;
-        for (int c = 0; c < C; ++c) {          // channel order of the exact pass and of the oracle
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {           // 8 loads in flight, then the ordered accumulation
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load_as_float(col + (int64_t)(c + u) * n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fma((double)v[u], (double)v[u], s);
+        }
+        for (; c < C; ++c) {                   // channel order of the exact pass and of the oracle
             const double v = (double)load_as_float(col + (int64_t)c * n);
             s = fma(v, v, s);
         }
@@ -308,21 +316,28 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
 // ---------------------------------------------------------------------------------------------
 // 2b. filter pass, bfloat16 MFMA (v_mfma_f32_32x32x16_bf16, float32 accumulation)
 //
-// One 512-thread block = 256 queries x (a split of) all references.  The 8 waves form a 4 (query
-// groups of 64) x 2 (reference halves of 64) grid.  Both operands are channel-major in memory
-// (C rows of cells), which is the TRANSPOSE of what the MFMA fragments want (8 consecutive channels
-// per lane), so tiles are copied to LDS as they are and read back with ds_read_b64_tr_b16.  The
-// query fragments of a wave are read once and stay in registers (C/2 VGPRs) for the whole kernel;
-// reference chunks of 128 cells stream through a double-buffered LDS image, prefetched through
-// registers one chunk ahead.  Rows are padded by 64 bytes so that the four rows a transposed read
-// touches fall on four different bank quarters.
+// One 256-thread block = 256 queries x (a split of) all references; wave w owns queries
+// [64w, 64w+64) and every wave sees every reference.  Two such blocks fit on a CU, and because they
+// run out of phase one block's chunk boundary (barrier, LDS refill) is covered by the other's MFMAs.
+// Both operands are channel-major in memory (C rows of cells), the TRANSPOSE of what the MFMA
+// fragments want (8 consecutive channels per lane), so tiles are copied to LDS as they are and read
+// back with ds_read_b64_tr_b16.  A wave's query fragments are read once and stay in registers
+// (C/2 VGPRs) for the whole kernel; reference chunks of 64 cells stream through a ring of three
+// LDS images, fetched into registers two chunks ahead and written to LDS one chunk ahead, with the
+// block barrier in the MIDDLE of a chunk so that no wave ever waits on an LDS read right after it.  LDS rows are padded so that the four
+// rows a transposed read touches fall on four different bank quarters.
 // ---------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef ISPA_ABLATE
+#define ISPA_ABLATE 0                // development switch: 1 = no top-list update, 2 = no chunk streaming
+#endif
 constexpr int kBQ = 256;             // queries per block
-constexpr int kBThreads = 512;
-constexpr int kRStride = 256 + 64;   // bytes per LDS row of 128 bf16 reference cells
+constexpr int kBR = 64;              // references per chunk
+constexpr int kBThreads = 256;
+constexpr int kBSubStreams = 2;      // partial result streams per (tile, split): the two lane halves
+constexpr int kRStride = 128;        // bytes per LDS row of 64 bf16 reference cells (swizzled, not padded)
 constexpr int kQStride = 512 + 64;   // bytes per LDS row of 256 bf16 query cells
 
 __device__ __forceinline__ bf16x8 tr_frag(const char *lds_row0_col, int stride) {
@@ -337,8 +352,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *lds_row0_col, int stride) 
     return u.v;
 }
 
+template <int KS>
+constexpr int bf16_filter_lds_bytes() {
+    constexpr int stream = 3 * 16 * KS * kRStride + 3 * kBR * (int)sizeof(float);
+    constexpr int qimage = 16 * KS * kQStride;
+    return stream > qimage ? stream : qimage;
+}
+
 template <int KS, int K>
-__global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
+__global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx) {
@@ -346,10 +368,9 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
     constexpr int kRBuf = C * kRStride;                 // one reference chunk image
     constexpr int kSeg = KS / 2;                        // 16-byte segments per thread per chunk
     static_assert(KS % 2 == 0 && KS <= 8, "C must be a multiple of 32, at most 128");
-    static_assert(C * kQStride <= 2 * kRBuf, "query staging must fit in the reference buffers");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char *rbuf = lds;                                   // 2 * kRBuf
-    float *nhbuf = reinterpret_cast<float *>(lds + 2 * kRBuf);   // 2 * 128 floats
+    char *rbuf = lds;                                   // ring of 3 chunk images
+    float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);   // ring of 3 x kBR floats
 
     int bid = xcd_order(blockIdx.x, gridDim.x);
     const int qt = bid % n_qtiles;
@@ -358,8 +379,7 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
     const int b = bid / nsplit;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wq = wave & 3, wr = wave >> 2;
+    const int lane = tid & 63, wq = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     // transposed-read addressing: 16-lane group g covers columns 16*(g&1).., channels 8*(g>>1)..
     const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -371,53 +391,53 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
     const int64_t q0 = (int64_t)qt * kBQ;
     const int64_t rbeg = (int64_t)split * refs_per_split;
     const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
 
     // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
-    for (int e = 0; e < KS; ++e) {                       // C rows x 32 segments of 8 queries
+#pragma unroll
+    for (int e = 0; e < 2 * KS; ++e) {                   // C rows x 32 segments of 8 queries
         const int seg = tid + kBThreads * e;
         const int row = seg >> 5, col = (seg & 31) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)row * nq + q0 + col);
         *reinterpret_cast<uint4 *>(lds + row * kQStride + col * 2) = v;
     }
-    // first reference chunk: global -> registers while the query tile settles
-    // Branch-free so that the chunk loop is one basic block: out-of-range lanes load from a valid
-    // address (the row start) and the value is replaced by zero / -inf afterwards.
-    uint4 pre[kSeg];
-    float pre_nh = 0.f;
-    unsigned pre_ok = 0;         // bit e: segment e in range, bit 31: the norm entry in range
-    auto prefetch = [&](int64_t r0) {
-        pre_ok = 0;
-#pragma unroll
-        for (int e = 0; e < kSeg; ++e) {                 // C rows x 16 segments of 8 references
-            const int seg = tid + kBThreads * e;
-            const int row = seg >> 4, col = (seg & 15) * 8;
-            const bool ok = r0 + col < rend;
-            pre_ok |= ok ? 1u << e : 0u;
-            pre[e] = *reinterpret_cast<const uint4 *>(rb + (int64_t)row * nr + (ok ? r0 + col : 0));
-        }
-        const bool okn = r0 + (tid & (kTR - 1)) < rend;
-        pre_ok |= okn ? 0x80000000u : 0u;
-        pre_nh = nhb[okn ? r0 + (tid & (kTR - 1)) : 0];
-    };
-    // the masking is applied here, long after the loads were issued, so that nothing waits on them early
-    auto commit = [&](int buf) {
+    // Reference chunk -> LDS slot, 1 KiB (8 rows x 128 B) per wave instruction, kSeg instructions
+    // per wave.  Lane l lands on row l>>3, 16-byte segment l&7 of its 8 rows; it fetches the
+    // segment whose index has bit 2 flipped when the row index has bit 1 set (the half swap).
+    // Columns past the end of this block's reference range re-read the row start: real, finite
+    // feature values whose scores the masked norm entry pushes out of contention.
+    // The loads are issued from inline asm: the compiler neither counts them nor orders LDS reads
+    // behind them (it would wait for every LDS-direct load before the next ds_read); the wait is the
+    // explicit vmcnt(0) in front of the mid-chunk barrier.
+    const int st_seg = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    const int wq_u = __builtin_amdgcn_readfirstlane(wq);
+    const uint16_t *st_row = rb + (int64_t)(8 * wq_u * kSeg + (lane >> 3)) * nr;   // this lane's first row
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)rbuf;
+    auto stage = [&](int64_t r0, int slot) {
+        const int64_t col = r0 + st_seg * 8;
+        const uint16_t *src = st_row + (col < rend ? col : 0);
 #pragma unroll
         for (int e = 0; e < kSeg; ++e) {
-            const int seg = tid + kBThreads * e;
-            const int row = seg >> 4, col = (seg & 15) * 8;
-            const bool ok = (pre_ok >> e) & 1u;
-            uint4 v;
-            v.x = ok ? pre[e].x : 0u;
-            v.y = ok ? pre[e].y : 0u;
-            v.z = ok ? pre[e].z : 0u;
-            v.w = ok ? pre[e].w : 0u;
-            *reinterpret_cast<uint4 *>(rbuf + buf * kRBuf + row * kRStride + col * 2) = v;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + (wq_u * kSeg + e) * 1024);
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src + (int64_t)e * 8 * nr), "s"(dst)
+                : "memory");
         }
-        nhbuf[buf * kTR + (tid & (kTR - 1))] = (pre_ok >> 31) ? pre_nh : kNegInf;   // four waves write the same values
     };
-    if (nchunks > 0) prefetch(rbeg);
+    // norm entry of the chunk after next, parked in a register; the masking is applied when it is
+    // written to LDS, so that nothing waits for the load (and, in order, for the LDS-direct loads
+    // issued before it) early
+    float pre_nh = 0.f;
+    bool pre_ok = false;
+    auto fetch_nh = [&](int64_t r0) {
+        pre_ok = r0 + (tid & (kBR - 1)) < rend;
+        pre_nh = nhb[pre_ok ? r0 + (tid & (kBR - 1)) : 0];
+    };
+    auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
     __syncthreads();
     bf16x8 bq[2][KS];
 #pragma unroll
@@ -426,17 +446,24 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         for (int ks = 0; ks < KS; ++ks)
             bq[qi][ks] = tr_frag(lds + (ks * 16 + tr_row) * kQStride + (wq * 64 + qi * 32 + tr_col) * 2, kQStride);
     __syncthreads();                                     // query image no longer needed
-    if (nchunks > 0) commit(0);
+    if (nchunks > 0) {
+        stage(clamp_chunk(0), 0);
+        stage(clamp_chunk(1), 1);
+        fetch_nh(clamp_chunk(0));
+        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        fetch_nh(clamp_chunk(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     typename ListFor<K, true>::type best[2];
     best[0].init();
     best[1].init();
 
-    // Each chunk is two half-steps (reference rows 0-31 and 32-63 of this wave's 64).  The MFMAs of
-    // one half-step are interleaved, in a pinned program order, with the top-list update of the
-    // previous half-step's accumulators, so the matrix pipe and the vector ALU work at the same
-    // time; the transposed LDS reads run one k-step ahead of their MFMAs.
+    // Each chunk is two half-steps (its reference rows 0-31 and 32-63).  The MFMAs of one half-step
+    // are interleaved, in a pinned program order, with the top-list update of the previous
+    // half-step's accumulators, so the matrix pipe and the vector ALU work at the same time; the
+    // transposed LDS reads run two k-steps ahead of their MFMAs.
     f32x16 acc_a[2], acc_b[2];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) acc_b[0][reg] = acc_b[1][reg] = kNegInf;   // nothing pending yet
@@ -448,7 +475,7 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         f32x16 v;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t = *reinterpret_cast<const float4 *>(nh + wr * 64 + ri * 32 + 8 * g + 4 * h);
+            const float4 t = *reinterpret_cast<const float4 *>(nh + ri * 32 + 8 * g + 4 * h);
             v[4 * g + 0] = t.x;
             v[4 * g + 1] = t.y;
             v[4 * g + 2] = t.z;
@@ -456,31 +483,32 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         }
         return v;
     };
+    const int rd_swap = (lane >> 3) & 1;                 // bit 1 of the channel rows this lane addresses
     auto frag = [&](const char *rimg, int ri, int ks) {
-        return tr_frag(rimg + (ks * 16 + tr_row) * kRStride + (wr * 64 + ri * 32 + tr_col) * 2, kRStride);
+        return tr_frag(rimg + (ks * 16 + tr_row) * kRStride + ((ri ^ rd_swap) * 32 + tr_col) * 2, kRStride);
     };
-    // MFMAs of half-step `ri` into `now`, top-list update of `prev` (half-step id prev_half).
-    // The transposed LDS reads run two k-steps ahead: a0 / a1 hold the fragments of k-steps 0 and 1
-    // on entry, and those of the next half-step (`next_img`, `next_ri`; has_next = false_type when
-    // its image is not in LDS yet) on exit.
-    auto half_step = [&](auto has_next, const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 &a0,
-                         bf16x8 &a1, const f32x16 &init, f32x16 (&now)[2], const f32x16 (&prev)[2],
-                         int prev_half) {
+    // MFMAs of half-step (`rimg`, `ri`) into `now`, top-list update of `prev` (half-step id
+    // prev_half).  a0 / a1 hold the fragments of k-steps 0 and 1 on entry and those of the next
+    // half-step (`next_img`, `next_ri`) on exit.
+    auto half_step = [&](const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 &a0, bf16x8 &a1,
+                         const f32x16 &init, f32x16 (&now)[2], const f32x16 (&prev)[2], int prev_half) {
         best[0].begin_half(prev_half);
         best[1].begin_half(prev_half);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 a2 = a1;
-            if (ks + 2 < KS)
-                a2 = frag(rimg, ri, ks + 2);
-            else if (decltype(has_next)::value)
-                a2 = frag(next_img, next_ri, ks + 2 - KS);
+            const bf16x8 a2 = ks + 2 < KS ? frag(rimg, ri, ks + 2) : frag(next_img, next_ri, ks + 2 - KS);
             now[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][ks], ks ? now[0] : init, 0, 0, 0);
 #pragma unroll
-            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) best[0].push(prev[0][reg], reg);
+            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
+                if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[0][reg]));
+                else best[0].push(prev[0][reg], reg);
+            }
             now[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][ks], ks ? now[1] : init, 0, 0, 0);
 #pragma unroll
-            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) best[1].push(prev[1][reg], reg);
+            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
+                if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[1][reg]));
+                else best[1].push(prev[1][reg], reg);
+            }
             __builtin_amdgcn_sched_barrier(0);
             a0 = a1;
             a1 = a2;
@@ -489,22 +517,36 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         best[1].end_half();
     };
 
+    // chunk c lives in ring slot c % 3.  Mid-chunk c: the norm entries of chunk c+1 go to LDS, all
+    // LDS-direct loads of chunk c+1 (issued a chunk ago) are waited for, barrier; then the loads of
+    // chunk c+2 are issued into the slot whose last readers worked on chunk c-1 and have all passed
+    // this barrier.  Everything read right after the barrier was complete before it and is not
+    // needed for another half-step.
+    bf16x8 a0, a1;
+    f32x16 init_a;
+    if (nchunks > 0) {
+        a0 = frag(rbuf, 0, 0);
+        a1 = frag(rbuf, 0, 1);
+        init_a = load_init(nhbuf, 0);
+    }
+    int slot = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int buf = chunk & 1;
-        // the last iteration re-fetches its own chunk into the idle buffer: harmless, and it keeps
-        // the loop body free of branches
-        prefetch(rbeg + (int64_t)(chunk + 1 < nchunks ? chunk + 1 : chunk) * kTR);
-        const char *rimg = rbuf + buf * kRBuf;
-        const float *nh = nhbuf + buf * kTR;
-        bf16x8 a0 = frag(rimg, 0, 0), a1 = frag(rimg, 0, 1);
-        const f32x16 init0 = load_init(nh, 0);
+        const int next_slot = slot == 2 ? 0 : slot + 1;
+        const int after_slot = next_slot == 2 ? 0 : next_slot + 1;
+        const char *rimg = rbuf + slot * kRBuf;
+        const char *next_img = rbuf + next_slot * kRBuf;
+        const f32x16 init_b = load_init(nhbuf + slot * kBR, 1);
         __builtin_amdgcn_sched_barrier(0);
-        half_step(std::true_type(), rimg, 0, rimg, 1, a0, a1, init0, acc_a, acc_b, chunk * 2 - 1);
-        const f32x16 init1 = load_init(nh, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        half_step(std::false_type(), rimg, 1, rimg, 0, a0, a1, init1, acc_b, acc_a, chunk * 2);
-        commit(buf ^ 1);      // the loads were issued a whole chunk ago
+        half_step(rimg, 0, rimg, 1, a0, a1, init_a, acc_a, acc_b, chunk * 2 - 1);
+        nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;   // all waves write the same values
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (ISPA_ABLATE != 2) stage(clamp_chunk(chunk + 2), after_slot);
+        fetch_nh(clamp_chunk(chunk + 2));
+        init_a = load_init(nhbuf + next_slot * kBR, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(rimg, 1, next_img, 0, a0, a1, init_b, acc_b, acc_a, chunk * 2);
+        slot = next_slot;
     }
     if (nchunks > 0) {
 #pragma unroll
@@ -516,8 +558,9 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         }
     }
 
-    const int nparts = nsplit * kSubStreams;
-    const int part = split * kSubStreams + wr * 2 + h;
+    // one partial stream per (split, lane half); finalize merges them
+    const int nparts = nsplit * kBSubStreams;
+    const int part = split * kBSubStreams + h;
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
@@ -526,9 +569,9 @@ __global__ __launch_bounds__(kBThreads) void nn_filter_bf16_kernel(
         for (int s = 0; s <= K; ++s) {
             const int code = best[qi].code(s);
             int ref = -1;
-            if (code >= 0) {
-                const int reg = code & 15, ri = (code >> 4) & 1;
-                ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+            if (code >= 0) {                             // code = half-step * 16 + accumulator register
+                const int reg = code & 15;
+                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
             }
             const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
             part_val[o] = best[qi].value(s);
@@ -748,18 +791,20 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
     p.bf16_mfma = dtype == ISPA_BF16 && C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
     p.tq = p.bf16_mfma ? kBQ : kTQ;
+    const int chunk_refs = p.bf16_mfma ? kBR : kTR;
+    const int substreams = p.bf16_mfma ? kBSubStreams : kSubStreams;
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
     p.ktemplate = k == 1 ? 1 : (k <= 5 ? 5 : kMaxK);
-    const int64_t chunks = (nr + kTR - 1) / kTR;
+    const int64_t chunks = (nr + chunk_refs - 1) / chunk_refs;
     // enough workgroups to fill 256 CUs a few times over, without going below 2 chunks per split
-    const int64_t want = p.bf16_mfma ? 512 : 1024;
+    const int64_t want = 1024;
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
     while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
     const int64_t cps = (chunks + nsplit - 1) / nsplit;
-    p.refs_per_split = cps * kTR;
+    p.refs_per_split = cps * chunk_refs;
     p.nsplit = (int)((chunks + cps - 1) / cps);
-    p.nparts = p.nsplit * kSubStreams;
+    p.nparts = p.nsplit * substreams;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -782,7 +827,7 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
 template <int KS, int KT>
 int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                 int64_t nr, const Plan &p, float *pval, int *pidx) {
-    constexpr int lds_bytes = 2 * 16 * KS * kRStride + 2 * kTR * (int)sizeof(float);
+    constexpr int lds_bytes = bf16_filter_lds_bytes<KS>();
     static bool configured = false;       // per instantiation
     if (!configured) {
         ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT>),
