@@ -675,7 +675,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, const T *__restrict__ r,
                                                        const double *__restrict__ qq64,
                                                        const double *__restrict__ rr64, int C, int64_t nq,
-                                                       int64_t nr, int k_out, int index_base,
+                                                       int64_t nr, int k_out, int index_base, int vec_ok,
                                                        const int *__restrict__ amb_count,
                                                        const int *__restrict__ amb_list,
                                                        float *__restrict__ dist, int *__restrict__ idx) {
@@ -703,38 +703,67 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
             bd[s] = __builtin_inf();
             bj[s] = 0x7fffffff;
         }
-        for (int64_t j0 = threadIdx.x; j0 < nr; j0 += 1024) {
-            double dot[4] = {0.0, 0.0, 0.0, 0.0};
-            const T *rp[4];
-            bool in[4];
+        auto consider = [&](double dot, int j) {
+            const double d = (qq + rrb[j]) - 2.0 * dot;
+            // insert into the thread-local ascending list (static indexing keeps it in registers)
+            double cd = d;
+            int cj = j;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                in[u] = j0 + 256 * u < nr;
-                rp[u] = rb + (in[u] ? j0 + 256 * u : j0);
+            for (int s = 0; s < kMaxK; ++s) {
+                const bool lt = key_less(cd, cj, bd[s], bj[s]);
+                const double td = lt ? bd[s] : cd;
+                const int tj = lt ? bj[s] : cj;
+                bd[s] = lt ? cd : bd[s];
+                bj[s] = lt ? cj : bj[s];
+                cd = td;
+                cj = tj;
             }
-            for (int c = 0; c < C; ++c) {
-                const double qv = qs[c];
+        };
+        constexpr int V = 16 / (int)sizeof(T);          // cells per 16-byte load: 4 float, 8 bfloat16
+        if (vec_ok) {
+            // V consecutive references per thread and load; every chain keeps the channel order
+            for (int64_t j0 = (int64_t)threadIdx.x * V; j0 < nr; j0 += 256 * V) {
+                double dot[V];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) dot[u] = fma(qv, (double)load_as_float(rp[u] + (int64_t)c * nr), dot[u]);
-            }
+                for (int u = 0; u < V; ++u) dot[u] = 0.0;
+                const T *rp = rb + j0;
+#pragma unroll 4
+                for (int c = 0; c < C; ++c) {
+                    const double qv = qs[c];
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(rp + (int64_t)c * nr);
+                    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!in[u]) continue;
-                const int j = (int)(j0 + 256 * u);
-                const double d = (qq + rrb[j]) - 2.0 * dot[u];
-                // insert into the thread-local ascending list (static indexing keeps it in registers)
-                double cd = d;
-                int cj = j;
-#pragma unroll
-                for (int s = 0; s < kMaxK; ++s) {
-                    const bool lt = key_less(cd, cj, bd[s], bj[s]);
-                    const double td = lt ? bd[s] : cd;
-                    const int tj = lt ? bj[s] : cj;
-                    bd[s] = lt ? cd : bd[s];
-                    bj[s] = lt ? cj : bj[s];
-                    cd = td;
-                    cj = tj;
+                    for (int u = 0; u < V; ++u) {
+                        float rv;
+                        if (sizeof(T) == 4)
+                            rv = __uint_as_float(w[u & 3]);
+                        else
+                            rv = __uint_as_float((u & 1) ? (w[u >> 1] & 0xffff0000u) : (w[u >> 1] << 16));
+                        dot[u] = fma(qv, (double)rv, dot[u]);
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < V; ++u) consider(dot[u], (int)(j0 + u));
+            }
+        } else {
+            for (int64_t j0 = threadIdx.x; j0 < nr; j0 += 1024) {
+                double dot[4] = {0.0, 0.0, 0.0, 0.0};
+                const T *rp[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    in[u] = j0 + 256 * u < nr;
+                    rp[u] = rb + (in[u] ? j0 + 256 * u : j0);
+                }
+                for (int c = 0; c < C; ++c) {
+                    const double qv = qs[c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        dot[u] = fma(qv, (double)load_as_float(rp[u] + (int64_t)c * nr), dot[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (in[u]) consider(dot[u], (int)(j0 + 256 * u));
             }
         }
         // k_out rounds of block-wide lexicographic minimum over the thread-local heads
@@ -880,10 +909,10 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const float u = 5.9604645e-8f;   // 2^-24
     if (p.bf16_mfma) {
         // rounding model of v_mfma_f32_32x32x16_bf16: products of two bf16 are exact in float32; each
-        // instruction adds 16 of them to the accumulator with a total error of at most 4 units in
+        // instruction adds 16 of them to the accumulator with a total error of at most 2 units in
         // the last place of the largest magnitude involved.  (C/16 + 1) such steps, two scores
         // compared, 1.25 safety.  tests/test_gpu_parity.py measures the real error against this.
-        err_rel = 2.f * 1.25f * 4.f * (float)(C / 16 + 1) * 2.f * u;
+        err_rel = 2.f * 1.25f * 2.f * (float)(C / 16 + 1) * 2.f * u;
         if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
         const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
         int rc;
@@ -925,8 +954,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096);
     const size_t esmem = (size_t)C * sizeof(double) + 256 * (sizeof(double) + 2 * sizeof(int));
     ISPA_REQUIRE(esmem <= 64 * 1024, "too many channels (%d) for the exact pass", C);
+    // 16-byte loads of consecutive references need aligned rows
+    const int evec = 16 / (int)sizeof(T);
+    const int exact_vec_ok = nr % evec == 0 && (uintptr_t)r % 16 == 0;
     hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr, k,
-                       index_base, count, list, dist, idx);
+                       index_base, exact_vec_ok, count, list, dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
     if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;

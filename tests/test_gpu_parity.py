@@ -361,9 +361,15 @@ def test_nn_bf16_shapes_and_error_model(pea):
             _, want_d = cnative.nn_exact(qr[i], rr[i], 1, 1)
             qn = np.sqrt((qr[i].astype(np.float64) ** 2).sum(0))
             rmax2 = (rr[i].astype(np.float64) ** 2).sum(0).max()
-            bound = 4.0 * 9 * 2 * 2.0 ** -24 * (qn * np.sqrt(rmax2) + 0.5 * rmax2)    # per score, no safety
+            scale = qn * np.sqrt(rmax2) + 0.5 * rmax2
+            bound = 2.0 * 9 * 2 * 2.0 ** -24 * scale          # the library's per-score MFMA model, no safety
+            tag = 2.0 ** -19 * scale                          # 4 tagged mantissa bits
             err = np.abs(dist[i].cpu().numpy().astype(np.float64) - want_d)[0] / 2.0
-            assert np.all(err <= 0.25 * bound + 2.0 ** -22 * (qn ** 2)), float((err / bound).max())
+            # the distance also carries float32 roundings of |q|^2 and of the final subtraction
+            slack = 2.0 ** -22 * (qn ** 2 + scale)
+            worst = float(((err - tag - slack) / bound).max())
+            print("bf16 filter error / model bound:", worst)
+            assert worst <= 0.5, worst
 
 
 def test_nn_top5_c256(pea):
