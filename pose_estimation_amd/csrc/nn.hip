@@ -22,7 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTQ = 128;       // queries per workgroup tile
 constexpr int kTR = 128;       // references per chunk
-constexpr int kKC = 32;        // channels per LDS stage
+constexpr int kKC = 16;        // channels per LDS stage
+constexpr int kGroups = kKC / 8; // float4 groups per thread per staged tile
 constexpr int kThreads = 256;  // 4 waves: 2 (reference halves) x 2 (query halves)
 constexpr int kSubStreams = 4; // partial result streams per (tile, split): wave-row x lane-half
 constexpr int kMaxK = 8;
@@ -177,13 +178,14 @@ struct ListFor<1, true> {
     typedef TagTop1 type;
 };
 
-// Guarded tile loader: rows = channels [c0, c0+kKC), columns = [n0, n0+128) of x (C, n) -> LDS.
+// Guarded tile loader: rows = channels [c0, c0+kKC), columns = [n0, n0+128) of x (C, n), converted
+// to float; kKC rows x 128 columns in groups of 4, kGroups groups per thread.  load_tile only issues
+// the global loads (into registers), store_tile writes them to LDS a stage later.
 template <typename T>
-__device__ __forceinline__ void stage_tile(const T *__restrict__ x, int C, int64_t n, int c0, int64_t n0,
-                                           float (*__restrict__ dst)[kTQ], bool vec_ok) {
-    // 32 rows x 128 columns = 1024 groups of 4; 4 groups per thread
+__device__ __forceinline__ void load_tile(const T *__restrict__ x, int C, int64_t n, int c0, int64_t n0,
+                                          float4 (&regs)[kGroups], bool vec_ok) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < kGroups; ++e) {
         const int g = threadIdx.x + kThreads * e;
         const int row = g >> 5;
         const int col = (g & 31) * 4;
@@ -209,18 +211,28 @@ __device__ __forceinline__ void stage_tile(const T *__restrict__ x, int C, int64
                 if (nn + 3 < n) val.w = load_as_float(src + 3);
             }
         }
-        *reinterpret_cast<float4 *>(&dst[row][col]) = val;
+        regs[e] = val;
+    }
+}
+
+__device__ __forceinline__ void store_tile(const float4 (&regs)[kGroups], float (*__restrict__ dst)[kTQ]) {
+#pragma unroll
+    for (int e = 0; e < kGroups; ++e) {
+        const int g = threadIdx.x + kThreads * e;
+        *reinterpret_cast<float4 *>(&dst[g >> 5][(g & 31) * 4]) = regs[e];
     }
 }
 
 template <typename T, int K>
-__global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
+__global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel(
     const T *__restrict__ q, const T *__restrict__ r, const float *__restrict__ rnh, int C, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) float Qs[kKC][kTQ];
-    __shared__ __attribute__((aligned(16))) float Rs[kKC][kTR];
-    __shared__ float Nh[kTR];
+    // two LDS stages of (kKC channels x 128 queries, kKC channels x 128 references): while the MFMAs
+    // consume one, the global loads of the next are in flight into registers
+    __shared__ __attribute__((aligned(16))) float Qs[2][kKC][kTQ];
+    __shared__ __attribute__((aligned(16))) float Rs[2][kKC][kTR];
+    __shared__ float Nh[2][kTR];
 
     // block -> (pair, split, query tile)
     int bid = xcd_order(blockIdx.x, gridDim.x);
@@ -240,46 +252,77 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_kernel(
     const int64_t q0 = (int64_t)qt * kTQ;
     const int64_t rbeg = (int64_t)split * refs_per_split;
     const int64_t rend = min(rbeg + refs_per_split, nr);
+    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+    const int nk = (C + kKC - 1) / kKC;
+    const int total = nchunks * nk;
 
     TopList<K> best[2];
     best[0].init();
     best[1].init();
 
-    int chunk = 0;
-    for (int64_t r0 = rbeg; r0 < rend; r0 += kTR, ++chunk) {
-        __syncthreads();  // previous chunk's Nh / tiles fully consumed
-        if (threadIdx.x < kTR) {
-            const int64_t j = r0 + threadIdx.x;
-            Nh[threadIdx.x] = j < rend ? nhb[j] : kNegInf;
+    float4 qreg[kGroups], rreg[kGroups];
+    float nh_reg = kNegInf;
+    auto fetch = [&](int chunk, int ks) {
+        load_tile(qb, C, nq, ks * kKC, q0, qreg, vec_ok);
+        load_tile(rb, C, nr, ks * kKC, rbeg + (int64_t)chunk * kTR, rreg, vec_ok);
+        if (ks == 0 && threadIdx.x < kTR) {
+            const int64_t j = rbeg + (int64_t)chunk * kTR + threadIdx.x;
+            nh_reg = j < rend ? nhb[j] : kNegInf;
         }
-        __syncthreads();
+    };
+    auto park = [&](int buf, int chunk, int ks) {
+        store_tile(qreg, Qs[buf]);
+        store_tile(rreg, Rs[buf]);
+        if (ks == 0 && threadIdx.x < kTR) Nh[chunk & 1][threadIdx.x] = nh_reg;
+    };
+    if (total > 0) {
+        fetch(0, 0);
+        park(0, 0, 0);
+    }
+    __syncthreads();
+
+    int st = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
         f32x16 acc[2][2];
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const float init = Nh[wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+                const float init = Nh[chunk & 1][wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
                 acc[ri][0][reg] = init;
                 acc[ri][1][reg] = init;
             }
-        for (int c0 = 0; c0 < C; c0 += kKC) {
-            if (c0) __syncthreads();
-            stage_tile(qb, C, nq, c0, q0, Qs, vec_ok);
-            stage_tile(rb, C, nr, c0, r0, Rs, vec_ok);
-            __syncthreads();
-#pragma unroll 4
+        for (int ks = 0; ks < nk; ++ks, ++st) {
+            const int buf = st & 1;
+            const bool more = st + 1 < total;
+            const int nks = ks + 1 < nk ? ks + 1 : 0;
+            const int nchunk = ks + 1 < nk ? chunk : chunk + 1;
+            if (more) fetch(nchunk, nks);
+            // LDS operand reads run one k-step ahead of the MFMAs that use them
+            float a0 = Rs[buf][h][wr * 64 + l31], a1 = Rs[buf][h][wr * 64 + 32 + l31];
+            float b0 = Qs[buf][h][wq * 64 + l31], b1 = Qs[buf][h][wq * 64 + 32 + l31];
+#pragma unroll
             for (int kk = 0; kk < kKC; kk += 2) {
-                const float a0 = Rs[kk + h][wr * 64 + l31];
-                const float a1 = Rs[kk + h][wr * 64 + 32 + l31];
-                const float b0 = Qs[kk + h][wq * 64 + l31];
-                const float b1 = Qs[kk + h][wq * 64 + 32 + l31];
+                float a0n = a0, a1n = a1, b0n = b0, b1n = b1;
+                if (kk + 2 < kKC) {
+                    a0n = Rs[buf][kk + 2 + h][wr * 64 + l31];
+                    a1n = Rs[buf][kk + 2 + h][wr * 64 + 32 + l31];
+                    b0n = Qs[buf][kk + 2 + h][wq * 64 + l31];
+                    b1n = Qs[buf][kk + 2 + h][wq * 64 + 32 + l31];
+                }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = a0n;
+                a1 = a1n;
+                b0 = b0n;
+                b1 = b1n;
             }
+            if (more) park(buf ^ 1, nchunk, nks);
+            __syncthreads();
         }
-        // epilogue: this lane owns query column (wq*64 + qi*32 + l31) and 16 reference rows per tile
+        // this lane owns query column (wq*64 + qi*32 + l31) and 16 reference rows per tile
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
