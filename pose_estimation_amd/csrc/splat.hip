@@ -76,6 +76,74 @@ __global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__
     reinterpret_cast<double2 *>(flow)[(int64_t)m * side * side + pix] = val;
 }
 
+// Flow splat with the owner image of one horizontal band of one map in LDS: every block scans all
+// points of its map (coalesced), keeps per pixel the highest kept point index with LDS atomics, then
+// resolves its band and writes the flow rows.  No global atomics, no scratch image in HBM.
+constexpr int kBandPixels = 25088;   // 98 KiB owner band (half of a 224 x 224 map): one block per CU
+constexpr int kBandThreads = 1024;
+
+__global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *__restrict__ uv1,
+                                                                 const double *__restrict__ uv2,
+                                                                 const uint8_t *__restrict__ truth, int64_t n,
+                                                                 int spread, int side, int band_rows,
+                                                                 double *__restrict__ flow) {
+    extern __shared__ int owner[];
+    const int m = blockIdx.y;
+    const int row0 = blockIdx.x * band_rows;
+    const int row1 = min(row0 + band_rows, side);
+    const int npix = (row1 - row0) * side;
+    for (int p = threadIdx.x; p < npix; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    const double *a = uv1 + (int64_t)m * 3 * n;
+    const double *b = uv2 + (int64_t)m * 3 * n;
+    const uint8_t *t = truth + (int64_t)m * n;
+    // batches of 8 points per thread: all flag loads first, then all coordinate loads, then the
+    // LDS updates, so that many loads are in flight per wave
+    constexpr int kBatch = 8;
+    for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
+        bool keep[kBatch];
+        double pu[kBatch], pv[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            keep[e] = i < n && t[i < n ? i : 0] != 0;
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            pu[e] = keep[e] ? a[i] : 0.0;
+            pv[e] = keep[e] ? a[n + i] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            if (!keep[e]) continue;
+            int u, v;
+            if (!to_int(pu[e], u) || !to_int(pv[e], v)) continue;
+            int y0, y1, x0, x1;
+            py_slice(v, spread, side, y0, y1);
+            y0 = max(y0, row0);
+            y1 = min(y1, row1);
+            if (y0 >= y1) continue;
+            py_slice(u, spread, side, x0, x1);
+            const int tag = (int)(base + (int64_t)e * kBandThreads + threadIdx.x) + 1;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+        }
+    }
+    __syncthreads();
+    double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
+    for (int p = threadIdx.x; p < npix; p += kBandThreads) {
+        const int o = owner[p];
+        double2 val = make_double2(0.0, 0.0);
+        if (o > 0) {
+            const int64_t i = o - 1;
+            val.x = b[i] - a[i];
+            val.y = b[n + i] - a[n + i];
+        }
+        out[p] = val;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void depth_owner_kernel(const double *__restrict__ pt_render,
                                                                int64_t n, int H, int W, int radius,
                                                                int32_t *__restrict__ owner) {
@@ -160,10 +228,26 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
     ISPA_REQUIRE(n >= 0 && n_map >= 0 && n < (1ll << 31) - 1, "bad point count");
     ISPA_REQUIRE(side > 0 && side <= 16384 && spread >= 0 && spread <= 64, "bad side/spread");
     if (n_map == 0) return ISPA_OK;
-    ISPA_REQUIRE(owner_ws && flow, "null pointer");
+    ISPA_REQUIRE(flow && (owner_ws || side <= kBandPixels), "null pointer");
     ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)side * side;
+    if (side <= kBandPixels) {
+        // banded LDS path (owner_ws is not touched)
+        ISPA_REQUIRE(n == 0 || (uv1 && uv2 && truth), "null pointer");
+        const int band_rows = kBandPixels / side;
+        const int nbands = (side + band_rows - 1) / band_rows;
+        const size_t lds_bytes = (size_t)band_rows * side * sizeof(int);
+        static bool configured = false;
+        if (!configured) {
+            ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&flow_band_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBandPixels * (int)sizeof(int)));
+            configured = true;
+        }
+        hipLaunchKernelGGL(flow_band_kernel, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, uv1, uv2, truth,
+                           n, spread, side, band_rows, flow);
+        return ispa::check_launch("flow_band_kernel");
+    }
     ISPA_HIP(hipMemsetAsync(owner_ws, 0, npix * n_map * sizeof(int32_t), s));
     if (n > 0) {
         ISPA_REQUIRE(uv1 && uv2 && truth, "null pointer");
