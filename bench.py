@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--workload", choices=["nn", "project", "disparity"], default="nn",
+                    help="nn: dense NN correspondence (the headline); project: 100k points x 3600 poses "
+                         "projection + visibility + crop; disparity: make_disparity flow maps of 100k-point renders")
+    ap.add_argument("--poses", type=int, default=3600)
+    ap.add_argument("--maps", type=int, default=256)
+    ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step result all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -71,6 +77,151 @@ def cpu_baseline(grid, channels, k, budget_s):
                       f"(oracle.nn.nn_sgemm), BLAS threads = {cores}"}
 
 
+HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md
+
+
+def synthetic_scene(points, n_views, seed):
+    """Seeded cloud + per-view pose, depth image (z-buffer of the cloud, background 20) and crop."""
+    from oracle import geometry as og, zbuffer as ozb
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-0.4, 0.4, (points, 3))
+    params = np.stack([rs.uniform(0, 360, n_views), rs.uniform(-10, 35, n_views), rs.uniform(-5, 5, n_views),
+                       np.full(n_views, 3.0)], axis=1)
+    return pts, params
+
+
+def run_geometry(args, torch, dist, world, rank, dev):
+    """Workloads 'project' and 'disparity' (inputs resident in HBM, one GPU's share per rank)."""
+    import pose_estimation_amd as pea
+    from pose_estimation_amd import _abi, _device as dv
+    n = args.points
+    rs = np.random.RandomState(100 + rank)
+    pts = torch.from_numpy(rs.uniform(-0.4, 0.4, (n, 3))).to(dev)
+    st = lambda: dv.stream_ptr()
+    crop_one = torch.tensor([[100, 400, 300, 700]], dtype=torch.int32, device=dev)
+    if args.workload == "project":
+        P = args.poses
+        poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
+        poses = np.resize(poses, (P, 4))
+        cams = torch.from_numpy(pea.pt2render.camera_matrices(poses)).to(dev)
+        depth = torch.full((540, 960), 3.0, dtype=torch.float32, device=dev)
+        out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
+        truth = torch.empty((P, n), dtype=torch.uint8, device=dev)
+
+        def step():
+            _abi.check(_abi.lib.ispa_project_prune(pts.data_ptr(), n, cams.data_ptr(), P, depth.data_ptr(), 0, 540,
+                                                   960, 540, 950, 0.15, _abi.VIS_A, crop_one.data_ptr(), 0,
+                                                   out.data_ptr(), truth.data_ptr(), None, None, st()))
+        units, unit_name, recs = P, "pose-maps/s", 1
+        alg_bytes = [24.0 * n + 29.0 * n * P]
+        names = ["project_prune"]
+        workload = (f"projection + depth visibility (variant A) + crop remap of a {n}-point model at {P} poses "
+                    f"per GPU per step, float64 drop-in layout")
+    else:
+        M = args.maps
+        params = np.stack([rs.uniform(0, 360, M), rs.uniform(-10, 35, M), np.zeros(M), np.full(M, 3.0)], axis=1)
+        cams1 = torch.from_numpy(pea.pt2render.camera_matrices(params)).to(dev)
+        more = params.copy()
+        more[:, :2] += 10.0
+        cams2 = torch.from_numpy(pea.pt2render.camera_matrices(more)).to(dev)
+        depth = torch.full((M, 540, 960), 3.0, dtype=torch.float32, device=dev)
+        crops = crop_one.repeat(M, 1).contiguous()
+        uv1 = torch.empty((M, 3, n), dtype=torch.float64, device=dev)
+        uv2 = torch.empty((M, 3, n), dtype=torch.float64, device=dev)
+        t1 = torch.empty((M, n), dtype=torch.uint8, device=dev)
+        t2 = torch.empty((M, n), dtype=torch.uint8, device=dev)
+        flow = torch.empty((M, 224, 224, 2), dtype=torch.float64, device=dev)
+        owner = torch.empty((M, 224 * 224), dtype=torch.int32, device=dev)
+
+        def prune(cams, uv, t):
+            _abi.check(_abi.lib.ispa_project_prune(pts.data_ptr(), n, cams.data_ptr(), M, depth.data_ptr(), 1, 540,
+                                                   960, 540, 950, 0.15, _abi.VIS_A, crops.data_ptr(), 1,
+                                                   uv.data_ptr(), t.data_ptr(), None, None, st()))
+
+        def step():
+            prune(cams1, uv1, t1)
+            prune(cams2, uv2, t2)
+            _abi.check(_abi.lib.ispa_flow_splat(uv1.data_ptr(), uv2.data_ptr(), t1.data_ptr(), n, M, 2, 224,
+                                                owner.data_ptr(), flow.data_ptr(), st()))
+        units, unit_name, recs = M, "maps/s", 3
+        alg_bytes = [24.0 * n + 29.0 * n * M, 24.0 * n + 29.0 * n * M, (33.0 * n + 802816.0) * M]
+        names = ["project_prune", "project_prune", "flow_band"]
+        workload = (f"make_disparity flow maps: {M} renders per GPU per step of a {n}-point model "
+                    f"(2 x projection+visibility+crop, then the 224x224x2 float64 flow splat)")
+    for _ in range(args.warmup):
+        step()
+    _abi.check(_abi.lib.ispa_timing_enable(args.steps * recs))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = (ctypes.c_float * (args.steps * recs))()
+    cnt = ctypes.c_int(0)
+    _abi.check(_abi.lib.ispa_timing_collect(ms, args.steps * recs, ctypes.byref(cnt)))
+    _abi.check(_abi.lib.ispa_timing_enable(0))
+    per = [float(np.mean(ms[i:cnt.value:recs])) for i in range(recs)]
+    dom = int(np.argmax(per))
+    if rank != 0:
+        return
+    achieved = alg_bytes[dom] / (per[dom] * 1e-3) / 1e9
+    out_json = {
+        "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
+        "value": round(units * world * args.steps / elapsed, 2), "unit": unit_name, "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "points": n},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": names[dom],
+                     "kernel_ms": round(per[dom], 4), "bytes_per_launch": alg_bytes[dom],
+                     "all_kernels_ms": {f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out_json["cpu_baseline"] = cpu_baseline_geometry(args)
+    print(json.dumps(out_json))
+
+
+def cpu_baseline_geometry(args):
+    """The reference's algorithm shape on the host: numpy projection, per-point Python loops for the
+    depth test and the splat (oracle restatements of pt2render.py:43-55 and make_disparity_syn.py:65-68)."""
+    from oracle import disparity as odisp, geometry as og
+    n = args.points
+    rs = np.random.RandomState(0)
+    pts = rs.uniform(-0.4, 0.4, (n, 3))
+    depth = np.full((540, 960), 3.0, np.float32)
+    crop = [100, 400, 300, 700]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        params = [30.0 + done, 10.0, 0.0, 3.0]
+        r1 = og.get_3d_to_2d(pts, params)
+        t1 = og.depth_visibility_literal(r1, depth, "A")
+        c1, _ = og.crop_visibility_array(r1, crop)
+        if args.workload == "disparity":
+            r2 = og.get_3d_to_2d(pts, [params[0] + 10, params[1] + 10, 0.0, 3.0])
+            og.depth_visibility_literal(r2, depth, "A")
+            og.crop_visibility_array(r2, crop)
+            keep = t1 & c1
+            odisp.splat_flow_literal(r1[:, keep], (r2 - r1)[:, keep])
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or done >= 50:
+            break
+    what = "make_disparity images" if args.workload == "disparity" else "project+prune poses"
+    return {"value": round(done / el, 3), "unit": "maps/s" if args.workload == "disparity" else "pose-maps/s",
+            "cores": 1, "kind": "port",
+            "sample": f"{done} {what} of {n} points in {el:.1f} s; numpy projection + per-point Python loops as in "
+                      f"the reference (oracle.geometry.depth_visibility_literal, oracle.disparity.splat_flow_literal)"}
+
+
 def main():
     args = parse()
     import torch
@@ -93,6 +244,11 @@ def main():
     from pose_estimation_amd import _abi, sharding
 
     dev = torch.device("cuda", torch.cuda.current_device())
+    if args.workload != "nn":
+        run_geometry(args, torch, dist, world, rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     b, c, g = args.pairs, args.channels, args.grid
     n = g * g
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -136,8 +136,9 @@ int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t 
                  size_t workspace_bytes, int32_t *stats, void *stream);
 
 /* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
- * next n ispa_nn_topk calls of this process brackets its filter kernel -- the launch that does
- * the MFMA contraction -- with HIP events on the call's stream.  ispa_timing_collect waits for
+ * next n calls of ispa_nn_topk (its filter kernel, the launch that does the MFMA contraction),
+ * ispa_project, ispa_project_prune or ispa_flow_splat brackets its dominant kernel with HIP events
+ * on the call's stream.  ispa_timing_collect waits for
  * them, writes the elapsed milliseconds of the recorded calls to a HOST array and re-arms the
  * slots.  ispa_timing_enable(0) turns it off and releases the events.  Not thread-safe. */
 int ispa_timing_enable(int max_records);

@@ -38,6 +38,14 @@ inline int check_launch(const char *what) {
             return ::ispa::fail(ISPA_EHIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
+// Optional timing of the dominant kernel of a call with HIP events on the call's stream
+// (ispa_timing_enable / ispa_timing_collect).  begin/end are no-ops while no slot is armed.
+struct TimingSlot {
+    bool armed;
+};
+TimingSlot timing_begin(hipStream_t stream);
+void timing_end(const TimingSlot &slot, hipStream_t stream);
+
 inline unsigned blocks_for(int64_t work, int threads, int64_t cap = 1 << 20) {
     int64_t b = (work + threads - 1) / threads;
     if (b < 1) b = 1;

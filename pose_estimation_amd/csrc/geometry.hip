@@ -94,6 +94,16 @@ __device__ __forceinline__ void project_point(const double *__restrict__ P, doub
     v = rint(a[1] / a[2]);
 }
 
+// 16-byte streaming store: the projected coordinates are written once and read by later kernels
+// only, so they need not displace anything in the caches.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_stream(double *dst, const double2 &v) {
+    f64x2 t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<f64x2 *>(dst));
+}
+
 __global__ __launch_bounds__(kThreads) void project_kernel(const double *__restrict__ pts, int64_t n,
                                                            const double *__restrict__ cams,
                                                            int n_pose, int poses_per_block,
@@ -110,6 +120,28 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const double *__restr
         o[i] = u;
         o[n + i] = v;
         o[2 * n + i] = z;
+    }
+}
+
+// Two consecutive points per thread: 16-byte loads and stores (the widest coalesced access),
+// used when n is even so that every (pose, row) starts 16-byte aligned.
+__global__ __launch_bounds__(kThreads) void project2_kernel(const double *__restrict__ pts, int64_t n,
+                                                            const double *__restrict__ cams, int n_pose,
+                                                            int poses_per_block, double *__restrict__ out) {
+    const int64_t i2 = (int64_t)blockIdx.x * kThreads + threadIdx.x;       // pair index
+    if (2 * i2 >= n) return;
+    const double2 *src = reinterpret_cast<const double2 *>(pts + 6 * i2);
+    const double2 l0 = src[0], l1 = src[1], l2 = src[2];                      // x0 y0 | z0 x1 | y1 z1
+    const int p0 = blockIdx.y * poses_per_block;
+    const int p1 = min(p0 + poses_per_block, n_pose);
+    for (int p = p0; p < p1; ++p) {
+        double2 u, v, z;
+        project_point(cams + 12 * (int64_t)p, l0.x, l0.y, l1.x, u.x, v.x, z.x);
+        project_point(cams + 12 * (int64_t)p, l1.y, l2.x, l2.y, u.y, v.y, z.y);
+        double *o = out + (int64_t)p * 3 * n + 2 * i2;
+        store_stream(o, u);
+        store_stream(o + n, v);
+        store_stream(o + 2 * n, z);
     }
 }
 
@@ -176,6 +208,45 @@ __global__ __launch_bounds__(kThreads) void project_prune_kernel(
     }
 }
 
+template <int VARIANT>
+__global__ __launch_bounds__(kThreads) void project_prune2_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams, int n_pose,
+    int poses_per_block, const float *__restrict__ depth, int depth_per_pose, int H, int W, int ylim,
+    int xlim, double relax, const int32_t *__restrict__ crop, int crop_per_pose,
+    double *__restrict__ out, uint8_t *__restrict__ truth, uint8_t *__restrict__ truth_depth,
+    uint8_t *__restrict__ truth_crop) {
+    const int64_t i2 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (2 * i2 >= n) return;
+    const double2 *src = reinterpret_cast<const double2 *>(pts + 6 * i2);
+    const double2 l0 = src[0], l1 = src[1], l2 = src[2];
+    const int p0 = blockIdx.y * poses_per_block;
+    const int p1 = min(p0 + poses_per_block, n_pose);
+    for (int p = p0; p < p1; ++p) {
+        double2 u, v, z;
+        project_point(cams + 12 * (int64_t)p, l0.x, l0.y, l1.x, u.x, v.x, z.x);
+        project_point(cams + 12 * (int64_t)p, l1.y, l2.x, l2.y, u.y, v.y, z.y);
+        const float *d = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
+        const bool vis0 = depth_test<VARIANT>(u.x, v.x, z.x, d, H, W, ylim, xlim, relax);
+        const bool vis1 = depth_test<VARIANT>(u.y, v.y, z.y, d, H, W, ylim, xlim, relax);
+        bool in0 = true, in1 = true;
+        if (crop) {
+            const int32_t *c = crop + (crop_per_pose ? 4 * (int64_t)p : 0);
+            const CropXform cx = make_crop(c);
+            const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+            in0 = crop_apply(cx, tall, 1, u.x, v.x);
+            in1 = crop_apply(cx, tall, 1, u.y, v.y);
+        }
+        double *o = out + (int64_t)p * 3 * n + 2 * i2;
+        store_stream(o, u);
+        store_stream(o + n, v);
+        store_stream(o + 2 * n, z);
+        const int64_t t = (int64_t)p * n + 2 * i2;
+        *reinterpret_cast<uchar2 *>(truth + t) = make_uchar2(vis0 && in0, vis1 && in1);
+        if (truth_depth) *reinterpret_cast<uchar2 *>(truth_depth + t) = make_uchar2(vis0, vis1);
+        if (truth_crop) *reinterpret_cast<uchar2 *>(truth_crop + t) = make_uchar2(in0, in1);
+    }
+}
+
 int check_depth_args(const float *depth, int H, int W, int ylim, int xlim, int variant) {
     ISPA_REQUIRE(depth != nullptr, "depth map pointer is null");
     ISPA_REQUIRE(H > 0 && W > 0, "depth map shape (%d,%d) invalid", H, W);
@@ -200,11 +271,15 @@ extern "C" int ispa_project(const double *pts, int64_t n, const double *cams, in
     ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
     if (n == 0 || n_pose == 0) return ISPA_OK;
     ISPA_REQUIRE(pts && cams && out, "null pointer");
-    const int ppb = pick_poses_per_block(n, n_pose);
-    dim3 grid(ispa::blocks_for(n, kThreads), (n_pose + ppb - 1) / ppb);
+    const bool vec2 = n % 2 == 0 && ((uintptr_t)pts | (uintptr_t)out) % 16 == 0;
+    const int64_t work = vec2 ? n / 2 : n;
+    const int ppb = pick_poses_per_block(work, n_pose);
+    dim3 grid(ispa::blocks_for(work, kThreads), (n_pose + ppb - 1) / ppb);
     ISPA_REQUIRE(grid.y <= 65535, "too many poses per call (%d)", n_pose);
-    hipLaunchKernelGGL(project_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose,
-                       ppb, out);
+    const ispa::TimingSlot timed = ispa::timing_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(vec2 ? project2_kernel : project_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n,
+                       cams, n_pose, ppb, out);
+    ispa::timing_end(timed, (hipStream_t)stream);
     return ispa::check_launch("project_kernel");
 }
 
@@ -247,16 +322,20 @@ extern "C" int ispa_project_prune(const double *pts, int64_t n, const double *ca
     if (n == 0 || n_pose == 0) return ISPA_OK;
     ISPA_REQUIRE(pts && cams && out && truth, "null pointer");
     if (int rc = check_depth_args(depth, H, W, ylim, xlim, variant)) return rc;
-    const int ppb = pick_poses_per_block(n, n_pose);
-    dim3 grid(ispa::blocks_for(n, kThreads), (n_pose + ppb - 1) / ppb);
+    uintptr_t align = (uintptr_t)pts | (uintptr_t)out;
+    const bool vec2 = n % 2 == 0 && align % 16 == 0 && (uintptr_t)truth % 2 == 0 &&
+                      (uintptr_t)truth_depth % 2 == 0 && (uintptr_t)truth_crop % 2 == 0;
+    const int64_t work = vec2 ? n / 2 : n;
+    const int ppb = pick_poses_per_block(work, n_pose);
+    dim3 grid(ispa::blocks_for(work, kThreads), (n_pose + ppb - 1) / ppb);
     ISPA_REQUIRE(grid.y <= 65535, "too many poses per call (%d)", n_pose);
-    if (variant == ISPA_VIS_A)
-        hipLaunchKernelGGL(project_prune_kernel<ISPA_VIS_A>, grid, dim3(kThreads), 0, (hipStream_t)stream, pts,
-                           n, cams, n_pose, ppb, depth, depth_per_pose, H, W, ylim, xlim, relax, crop,
-                           crop_per_pose, out, truth, truth_depth, truth_crop);
-    else
-        hipLaunchKernelGGL(project_prune_kernel<ISPA_VIS_B>, grid, dim3(kThreads), 0, (hipStream_t)stream, pts,
-                           n, cams, n_pose, ppb, depth, depth_per_pose, H, W, ylim, xlim, relax, crop,
-                           crop_per_pose, out, truth, truth_depth, truth_crop);
+    auto kernel = variant == ISPA_VIS_A
+                      ? (vec2 ? project_prune2_kernel<ISPA_VIS_A> : project_prune_kernel<ISPA_VIS_A>)
+                      : (vec2 ? project_prune2_kernel<ISPA_VIS_B> : project_prune_kernel<ISPA_VIS_B>);
+    const ispa::TimingSlot timed = ispa::timing_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose, ppb, depth,
+                       depth_per_pose, H, W, ylim, xlim, relax, crop, crop_per_pose, out, truth, truth_depth,
+                       truth_crop);
+    ispa::timing_end(timed, (hipStream_t)stream);
     return ispa::check_launch("project_prune_kernel");
 }

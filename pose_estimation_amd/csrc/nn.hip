@@ -32,12 +32,6 @@ constexpr int kMaxK = 8;
 constexpr float kNegInf = -3.0e38f;
 constexpr float kAbsent = -1.0e38f;
 
-// Optional timing of the filter kernel (the dominant launch) with HIP events on the caller's stream.
-struct FilterTiming {
-    int capacity = 0, used = 0;
-    hipEvent_t *start = nullptr, *stop = nullptr;
-} g_timing;
-
 // Blocks b and b+8 share an XCD (and its L2).  Renumber so that each XCD walks a contiguous range
 // of logical ids: the query tiles of one image pair, which all stream the same reference map, then
 // run on one L2.  Bijective for any grid size; a pure speed choice.
@@ -946,8 +940,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const int64_t nblocks = (int64_t)B * p.nsplit * p.n_qtiles;
     ISPA_REQUIRE(nblocks < (1ll << 31), "problem too large for one launch");
     const dim3 grid((unsigned)nblocks);
-    const bool timed = g_timing.used < g_timing.capacity;
-    if (timed) (void)hipEventRecord(g_timing.start[g_timing.used], s);
+    const ispa::TimingSlot timed = ispa::timing_begin(s);
     float err_rel;
     const float u = 5.9604645e-8f;   // 2^-24
     if (p.bf16_mfma) {
@@ -980,7 +973,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
             hipLaunchKernelGGL((nn_filter_f32_kernel<T, kMaxK>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
                                p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
     }
-    if (timed) (void)hipEventRecord(g_timing.stop[g_timing.used++], s);
+    ispa::timing_end(timed, s);
     if (int rc = ispa::check_launch("nn_filter")) return rc;
 
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
@@ -1042,36 +1035,4 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
                    p, stats, s);
     return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, k, index_base, dist, idx,
                (char *)workspace, p, stats, s);
-}
-
-extern "C" int ispa_timing_enable(int max_records) {
-    ISPA_REQUIRE(max_records >= 0 && max_records <= 65536, "max_records out of range");
-    for (int i = 0; i < g_timing.capacity; ++i) {
-        (void)hipEventDestroy(g_timing.start[i]);
-        (void)hipEventDestroy(g_timing.stop[i]);
-    }
-    delete[] g_timing.start;
-    delete[] g_timing.stop;
-    g_timing = FilterTiming();
-    if (max_records == 0) return ISPA_OK;
-    g_timing.start = new hipEvent_t[max_records];
-    g_timing.stop = new hipEvent_t[max_records];
-    for (int i = 0; i < max_records; ++i) {
-        ISPA_HIP(hipEventCreate(&g_timing.start[i]));
-        ISPA_HIP(hipEventCreate(&g_timing.stop[i]));
-    }
-    g_timing.capacity = max_records;
-    return ISPA_OK;
-}
-
-extern "C" int ispa_timing_collect(float *host_ms, int capacity, int *host_count) {
-    ISPA_REQUIRE(host_ms && host_count && capacity >= 0, "null pointer");
-    int n = g_timing.used < capacity ? g_timing.used : capacity;
-    for (int i = 0; i < n; ++i) {
-        ISPA_HIP(hipEventSynchronize(g_timing.stop[i]));
-        ISPA_HIP(hipEventElapsedTime(&host_ms[i], g_timing.start[i], g_timing.stop[i]));
-    }
-    *host_count = n;
-    g_timing.used = 0;
-    return ISPA_OK;
 }

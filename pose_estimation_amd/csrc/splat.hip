@@ -244,8 +244,10 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kBandPixels * (int)sizeof(int)));
             configured = true;
         }
+        const ispa::TimingSlot timed = ispa::timing_begin(s);
         hipLaunchKernelGGL(flow_band_kernel, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, uv1, uv2, truth,
                            n, spread, side, band_rows, flow);
+        ispa::timing_end(timed, s);
         return ispa::check_launch("flow_band_kernel");
     }
     ISPA_HIP(hipMemsetAsync(owner_ws, 0, npix * n_map * sizeof(int32_t), s));
