@@ -80,6 +80,19 @@ def cpu_baseline(grid, channels, k, budget_s):
 HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md
 
 
+def measured_traffic(workload_key, kernel, is_default_shape):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs of this same bench command, gfx950 correction applied by
+    tools/pmc_summary.py); null when this run's shape is not the profiled one."""
+    if not is_default_shape:
+        return None
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return table[workload_key][kernel]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synthetic_scene(points, n_views, seed):
     """Seeded cloud + per-view pose, depth image (z-buffer of the cloud, background 20) and crop."""
     from oracle import geometry as og, zbuffer as ozb
@@ -181,7 +194,12 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "points": n},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": names[dom],
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": measured_traffic(args.workload, {"project_prune": "project_prune2_kernel",
+                                                                 "flow_band": "flow_band_kernel"}[names[dom]],
+                                                 n == 100000 and (args.poses == 3600 if args.workload == "project"
+                                                                  else args.maps == 256)),
+                     "kernel": names[dom],
                      "kernel_ms": round(per[dom], 4), "bytes_per_launch": alg_bytes[dom],
                      "all_kernels_ms": {f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}},
     }
@@ -315,7 +333,10 @@ def main():
                        "pairs_per_gpu": b, "grid": g, "channels": c, "k": args.k,
                        "result_allgather": bool(gather)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4),
+                         "traffic": measured_traffic("nn___dtype_" + args.dtype,
+                                                     "nn_filter_%s_kernel" % args.dtype,
+                                                     (b, g, c, args.k) == (512, 64, 128, 1)),
                          "kernel": "nn_filter", "kernel_ms": round(filt_ms, 4),
                          "flop_per_launch": flop_per_pair * b},
         }
