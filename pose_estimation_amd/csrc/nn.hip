@@ -12,6 +12,7 @@
 //                 the rounding bound of the filter is final, the others are queued
 //   4. exact      float64 re-scoring of every reference for the queued queries, in the channel
 //                 order the CPU oracle uses, so the index order is exact under all inputs
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -19,6 +20,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef ISPA_ABLATE
+#define ISPA_ABLATE 0   // development switch for timing-only builds (results are wrong when non-zero):
+#endif                  // bf16 filter 1 = no top-list update, 2 = no chunk streaming; f32 filter 4, 5, 6 = both
 
 constexpr int kTQ = 128;       // queries per workgroup tile
 constexpr int kTR = 128;       // references per chunk
@@ -217,7 +222,10 @@ __device__ __forceinline__ void store_tile(const float4 (&regs)[kGroups], float 
     }
 }
 
-template <typename T, int K>
+// DIRECT: tiles go global -> LDS with LDS-direct loads (no staging registers, no ds_write); needs
+// float input, 16-byte aligned rows and C a multiple of kKC.  Otherwise tiles pass through
+// registers with per-element guards and conversion.
+template <typename T, int K, bool DIRECT>
 __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel(
     const T *__restrict__ q, const T *__restrict__ r, const float *__restrict__ rnh, int C, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
@@ -256,21 +264,53 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
 
     float4 qreg[kGroups], rreg[kGroups];
     float nh_reg = kNegInf;
-    auto fetch = [&](int chunk, int ks) {
-        load_tile(qb, C, nq, ks * kKC, q0, qreg, vec_ok);
-        load_tile(rb, C, nr, ks * kKC, rbeg + (int64_t)chunk * kTR, rreg, vec_ok);
+    // LDS-direct path: one wave instruction moves 1 KiB = 2 tile rows; this wave owns kKC/4
+    // consecutive rows of the query tile and of the reference tile.  Columns past the end of the map
+    // re-read column 0 (finite values; masked references / unwritten queries).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+    auto direct_tile = [&](const T *x, int64_t n, int c0, int64_t n0, float (*dst)[kTQ]) {
+        const int64_t col = n0 + d_col < n ? n0 + d_col : 0;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(&dst[0][0]);
+#pragma unroll
+        for (int e = 0; e < kKC / 8; ++e) {
+            const int row = (kKC / 4) * wave_u + 2 * e;
+            const T *src = x + (int64_t)(c0 + row + d_row) * n + col;
+            const unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds0 + row * kTQ * 4);
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(ldsaddr)
+                : "memory");
+        }
+    };
+    // fetch(chunk, ks, buf): start moving stage (chunk, ks) towards LDS buffer `buf`
+    auto fetch = [&](int chunk, int ks, int buf) {
+        if (DIRECT) {
+            direct_tile(qb, nq, ks * kKC, q0, Qs[buf]);
+            direct_tile(rb, nr, ks * kKC, rbeg + (int64_t)chunk * kTR, Rs[buf]);
+        } else {
+            load_tile(qb, C, nq, ks * kKC, q0, qreg, vec_ok);
+            load_tile(rb, C, nr, ks * kKC, rbeg + (int64_t)chunk * kTR, rreg, vec_ok);
+        }
         if (ks == 0 && threadIdx.x < kTR) {
             const int64_t j = rbeg + (int64_t)chunk * kTR + threadIdx.x;
             nh_reg = j < rend ? nhb[j] : kNegInf;
         }
     };
+    // park(buf, chunk, ks): make that stage complete in LDS (followed by the block barrier)
     auto park = [&](int buf, int chunk, int ks) {
-        store_tile(qreg, Qs[buf]);
-        store_tile(rreg, Rs[buf]);
+        if (DIRECT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            store_tile(qreg, Qs[buf]);
+            store_tile(rreg, Rs[buf]);
+        }
         if (ks == 0 && threadIdx.x < kTR) Nh[chunk & 1][threadIdx.x] = nh_reg;
     };
     if (total > 0) {
-        fetch(0, 0);
+        fetch(0, 0, 0);
         park(0, 0, 0);
     }
     __syncthreads();
@@ -291,7 +331,7 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
             const bool more = st + 1 < total;
             const int nks = ks + 1 < nk ? ks + 1 : 0;
             const int nchunk = ks + 1 < nk ? chunk : chunk + 1;
-            if (more) fetch(nchunk, nks);
+            if (more && ISPA_ABLATE != 5 && ISPA_ABLATE != 6) fetch(nchunk, nks, buf ^ 1);
             // LDS operand reads run one k-step ahead of the MFMAs that use them
             float a0 = Rs[buf][h][wr * 64 + l31], a1 = Rs[buf][h][wr * 64 + 32 + l31];
             float b0 = Qs[buf][h][wq * 64 + l31], b1 = Qs[buf][h][wq * 64 + 32 + l31];
@@ -313,7 +353,7 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
                 b0 = b0n;
                 b1 = b1n;
             }
-            if (more) park(buf ^ 1, nchunk, nks);
+            if (more && ISPA_ABLATE != 5 && ISPA_ABLATE != 6) park(buf ^ 1, nchunk, nks);
             __syncthreads();
         }
         // this lane owns query column (wq*64 + qi*32 + l31) and 16 reference rows per tile
@@ -323,7 +363,10 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
             for (int ri = 0; ri < 2; ++ri) {
                 best[qi].begin_half(chunk * 2 + ri);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) best[qi].push(acc[ri][qi][reg], reg);
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (ISPA_ABLATE == 4 || ISPA_ABLATE == 6) asm volatile("" ::"v"(acc[ri][qi][reg]));
+                    else best[qi].push(acc[ri][qi][reg], reg);
+                }
                 best[qi].end_half();
             }
     }
@@ -367,9 +410,6 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef ISPA_ABLATE
-#define ISPA_ABLATE 0                // development switch: 1 = no top-list update, 2 = no chunk streaming
-#endif
 constexpr int kBQ = 256;             // queries per block
 constexpr int kBR = 64;              // references per chunk
 constexpr int kBThreads = 256;
@@ -867,6 +907,7 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
     while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
+    if (const char *force = getenv("ISPA_DEV_NSPLIT")) nsplit = atoi(force);   // development knob
     const int64_t cps = (chunks + nsplit - 1) / nsplit;
     p.refs_per_split = cps * chunk_refs;
     p.nsplit = (int)((chunks + cps - 1) / cps);
@@ -963,15 +1004,19 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         const int elem = (int)sizeof(T);
         const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
                            ((uintptr_t)r % (4 * elem) == 0);
-        if (p.ktemplate == 1)
-            hipLaunchKernelGGL((nn_filter_f32_kernel<T, 1>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
-                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
-        else if (p.ktemplate == 5)
-            hipLaunchKernelGGL((nn_filter_f32_kernel<T, 5>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
-                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
-        else
-            hipLaunchKernelGGL((nn_filter_f32_kernel<T, kMaxK>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,
-                               p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok);
+        const bool direct = sizeof(T) == 4 && vec_ok && C % kKC == 0 && (uintptr_t)q % 16 == 0 &&
+                            (uintptr_t)r % 16 == 0;
+#define ISPA_F32_FILTER(KT, D)                                                                                 \
+    hipLaunchKernelGGL((nn_filter_f32_kernel<T, KT, D>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,    \
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok)
+        if (p.ktemplate == 1) {
+            if (direct) ISPA_F32_FILTER(1, true); else ISPA_F32_FILTER(1, false);
+        } else if (p.ktemplate == 5) {
+            if (direct) ISPA_F32_FILTER(5, true); else ISPA_F32_FILTER(5, false);
+        } else {
+            if (direct) ISPA_F32_FILTER(kMaxK, true); else ISPA_F32_FILTER(kMaxK, false);
+        }
+#undef ISPA_F32_FILTER
     }
     ispa::timing_end(timed, s);
     if (int rc = ispa::check_launch("nn_filter")) return rc;
