@@ -14,6 +14,7 @@ import torch
 from . import _abi, _device as dv, io_utils
 
 _workspaces = {}
+_ws_bytes = {}
 
 
 def _workspace(nbytes):
@@ -48,8 +49,11 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False):
         raise ValueError("k must be in [1, 8]")
     dist = dv.empty((b, k, nq), torch.float32)
     ind = dv.empty((b, k, nq), torch.int32)
-    stats = torch.zeros(4, dtype=torch.int32, device=dv.device())
-    need = _abi.lib.ispa_nn_workspace_bytes(b, c, nq, nr, k)
+    stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
+    key = (b, c, nq, nr, k)
+    need = _ws_bytes.get(key)
+    if need is None:
+        need = _ws_bytes[key] = _abi.lib.ispa_nn_workspace_bytes(b, c, nq, nr, k)
     ws = _workspace(max(need, 256))
     _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), _abi.BF16 if bf16 else _abi.F32, b, c, nq, nr, k,
                                      int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
