@@ -54,28 +54,19 @@ __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict_
     const int64_t base = (int64_t)b * C * cells;
     for (int c = threadIdx.x; c < C; c += 256) tmpl[c] = f2r[base + (int64_t)c * cells + ky * grid + kx];
     __syncthreads();
-    constexpr int kPer = 8;      // up to 2048 cells per map
-    float corr[kPer];
+    // pass 1: relu(correlation) to the output, sum of exp; pass 2: every thread rescales the
+    // cells it wrote itself
+    float *o = out + ((int64_t)b * K + k) * cells;
     float esum = 0.f;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) {
-        const int p = threadIdx.x + 256 * e;
-        corr[e] = 0.f;
-        if (p < cells) {
-            float acc = 0.f;
-            for (int c = 0; c < C; ++c) acc = fmaf(tmpl[c], f1r[base + (int64_t)c * cells + p], acc);
-            acc = fmaxf(acc, 0.f);
-            corr[e] = acc;
-            esum += expf(acc);
-        }
+    for (int p = threadIdx.x; p < cells; p += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(tmpl[c], f1r[base + (int64_t)c * cells + p], acc);
+        acc = fmaxf(acc, 0.f);
+        o[p] = acc;
+        esum += expf(acc);
     }
     const float denom = block_sum(esum, scratch);
-    float *o = out + ((int64_t)b * K + k) * cells;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) {
-        const int p = threadIdx.x + 256 * e;
-        if (p < cells) o[p] = corr[e] / denom * 10.f;
-    }
+    for (int p = threadIdx.x; p < cells; p += 256) o[p] = o[p] / denom * 10.f;
 }
 
 // one block per (b, 64 columns of the second map); all rows p of the first map
@@ -159,7 +150,7 @@ extern "C" int ispa_resize_bilinear(const float *in, int B, int C, int H, int W,
 extern "C" int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
                                   int W, int K, int grid, float *out, float *workspace, void *stream) {
     ISPA_REQUIRE(B >= 0 && K >= 0 && C > 0 && H > 0 && W > 0 && grid > 0, "bad shape");
-    ISPA_REQUIRE(grid * grid <= 2048, "grid %d too large for this kernel (max 45)", grid);
+    ISPA_REQUIRE(grid <= 4096, "grid %d too large", grid);
     ISPA_REQUIRE(C <= 8192 && B <= 65535, "C or B too large");
     if (B == 0 || K == 0) return ISPA_OK;
     ISPA_REQUIRE(f1 && f2 && knn && out && workspace, "null pointer");

@@ -393,6 +393,45 @@ def test_nn_full_size_properties(pea):
     assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())       # sorted ascending
 
 
+def test_nn_config5_full_size_properties(pea):
+    """3 template views x (128x128 grid, 256-d), top-5: the largest BASELINE configuration."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(11)
+    r = torch.randn(3, 256, 128 * 128, device="cuda", generator=g)
+    r = r / r.norm(dim=1, keepdim=True)
+    perm = torch.stack([torch.randperm(128 * 128, device="cuda", generator=g) for _ in range(3)])
+    q = torch.gather(r, 2, perm[:, None, :].expand(-1, 256, -1)).contiguous()
+    for dt in (torch.float32, torch.bfloat16):
+        d5, i5 = pea.correspondence.dense_nn(q.to(dt), r.to(dt), 5, index_base=0)
+        assert torch.equal(i5[:, 0, :].long(), perm)               # every query finds itself first
+        assert float(d5[:, 0, :].abs().max()) <= 1e-5
+        assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())         # sorted ascending
+        assert bool((i5 >= 0).all()) and bool((i5 < 128 * 128).all())
+        # spot-check three queries of view 1 against the oracle
+        qs = q[1].to(dt).float().cpu().numpy()[:, :3]
+        want_i, _ = cnative.nn_exact(qs, r[1].to(dt).float().cpu().numpy(), 5, 0)
+        assert np.array_equal(i5[1, :, :3].cpu().numpy(), want_i)
+
+
+def test_projection_config4_pose_sweep(pea):
+    """100k points x 360 poses through the fused kernel: spot poses against the bit-exact twin."""
+    rs = np.random.RandomState(4)
+    pts = rs.uniform(-0.4, 0.4, (100000, 3))
+    poses = np.array([[az, 10.0, 0.0, 3.0] for az in range(360)], dtype=np.float64)
+    cams = pea.pt2render.camera_matrices(poses)
+    depth = np.full((540, 960), 3.0, np.float32)
+    truth, out = pea.run_proj.project_prune(pts, cams, depth, [100, 400, 300, 700])
+    assert out.shape == (360, 3, 100000)
+    for p in (0, 123, 359):
+        r = cnative.project_fma(pts, cams[p])
+        vis = og.depth_visibility_array_a(r, depth)[0]
+        ct, rc = og.crop_visibility_array(r, [100, 400, 300, 700])
+        assert np.array_equal(truth[p], vis & ct) and np.array_equal(out[p], rc)
+    # odd point count takes the scalar kernels
+    t2, o2 = pea.run_proj.project_prune(pts[:99999], cams[:2], depth, [100, 400, 300, 700])
+    assert np.array_equal(o2[1], out[1][:, :99999]) and np.array_equal(t2[1], truth[1][:99999])
+
+
 # ---------------------------------------------------------------- correlation maps
 @pytest.mark.parametrize("tag", ["b1k1", "b2k10", "b3k14"])
 def test_corr_eccv_golden(pea, golden_correlation, tag):
@@ -406,6 +445,18 @@ def test_corr_eccv_golden(pea, golden_correlation, tag):
     assert np.allclose(got, want, rtol=1e-4, atol=1e-7)       # 1e-4 relative (float32 bar)
     with pytest.raises(IndexError):
         layer.forward(f1, f2, np.array([[28, 0]]))
+
+
+def test_corr_eccv_large_grid(pea):
+    """config-5 analogue: K = 10 keypoint maps on a 128 x 128 grid of 256-d features."""
+    rs = np.random.RandomState(13)
+    f1 = _unit(rs, (1, 256, 128, 128))
+    f2 = _unit(rs, (1, 256, 128, 128))
+    knn = rs.randint(0, 128, (10, 2))
+    got = pea.correspondence.CorrelationMapLayer(grid=128).forward(f1, f2, knn)
+    want = ocorr.correlation_map_eccv(f1, f2, knn, grid=128)
+    assert got.shape == (1, 10, 128, 128)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-9)
 
 
 def test_resize_and_l2norm(pea, golden_correlation):
