@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--poses", type=int, default=3600)
     ap.add_argument("--maps", type=int, default=256)
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--unfused", action="store_true",
+                    help="disparity workload through project_prune x2 + flow_splat instead of the fused kernel")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step result all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -151,16 +153,28 @@ def run_geometry(args, torch, dist, world, rank, dev):
                                                    960, 540, 950, 0.15, _abi.VIS_A, crops.data_ptr(), 1,
                                                    uv.data_ptr(), t.data_ptr(), None, None, st()))
 
-        def step():
-            prune(cams1, uv1, t1)
-            prune(cams2, uv2, t2)
-            _abi.check(_abi.lib.ispa_flow_splat(uv1.data_ptr(), uv2.data_ptr(), t1.data_ptr(), n, M, 2, 224,
-                                                owner.data_ptr(), flow.data_ptr(), st()))
-        units, unit_name, recs = M, "maps/s", 3
-        alg_bytes = [24.0 * n + 29.0 * n * M, 24.0 * n + 29.0 * n * M, (33.0 * n + 802816.0) * M]
-        names = ["project_prune", "project_prune", "flow_band"]
-        workload = (f"make_disparity flow maps: {M} renders per GPU per step of a {n}-point model "
-                    f"(2 x projection+visibility+crop, then the 224x224x2 float64 flow splat)")
+        if args.unfused:
+            def step():
+                prune(cams1, uv1, t1)
+                prune(cams2, uv2, t2)
+                _abi.check(_abi.lib.ispa_flow_splat(uv1.data_ptr(), uv2.data_ptr(), t1.data_ptr(), n, M, 2, 224,
+                                                    owner.data_ptr(), flow.data_ptr(), st()))
+            units, unit_name, recs = M, "maps/s", 3
+            alg_bytes = [24.0 * n + 29.0 * n * M, 24.0 * n + 29.0 * n * M, (33.0 * n + 802816.0) * M]
+            names = ["project_prune", "project_prune", "flow_band"]
+            workload = (f"make_disparity flow maps: {M} renders per GPU per step of a {n}-point model "
+                        f"(2 x projection+visibility+crop, then the 224x224x2 float64 flow splat)")
+        else:
+            def step():
+                _abi.check(_abi.lib.ispa_make_disparity(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
+                                                        depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
+                                                        crops.data_ptr(), 1, 2, flow.data_ptr(), st()))
+            units, unit_name, recs = M, "maps/s", 1
+            # fused: points read once per map, one depth gather per point, the flow map written
+            alg_bytes = [(24.0 * n + 4.0 * n + 802816.0) * M]
+            names = ["make_disparity"]
+            workload = (f"make_disparity flow maps, fused kernel: {M} renders per GPU per step of a {n}-point "
+                        f"model (projection at 2 poses, depth visibility, crop, 224x224x2 float64 flow splat)")
     for _ in range(args.warmup):
         step()
     _abi.check(_abi.lib.ispa_timing_enable(args.steps * recs))
@@ -195,8 +209,10 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "config": {"workload": workload, "points": n},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic(args.workload, {"project_prune": "project_prune2_kernel",
-                                                                 "flow_band": "flow_band_kernel"}[names[dom]],
+                     "traffic": measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
+                                                 {"project_prune": "project_prune2_kernel",
+                                                  "flow_band": "flow_band_kernel",
+                                                  "make_disparity": "make_disparity_kernel"}[names[dom]],
                                                  n == 100000 and (args.poses == 3600 if args.workload == "project"
                                                                   else args.maps == 256)),
                      "kernel": names[dom],

@@ -99,6 +99,17 @@ int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, 
                     int n_map, int spread, int side, int32_t *owner_ws, double *flow,
                     void *stream);
 
+/* Body of make_disparity for a batch of renders of one model, fused
+ *   data_creator/make_disparity_syn.py:44-68 (get_3d_to_2d + prune_pts at the render's pose and at
+ *   the pose turned by (10,10), masking by the first pose's truth, flow splat).
+ * pts (n,3) f64; cams1, cams2 (n_map,3,4) f64; depth (n_map,H,W) f32 or one shared (H,W);
+ * crop (n_map,4) int32 or one shared row; flow (n_map,224,224,2) f64.  Same results as
+ * ispa_project_prune x 2 + ispa_flow_splat without materialising the projected coordinates. */
+int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const double *cams2,
+                        int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
+                        int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
+                        double *flow, void *stream);
+
 /* get_pt_depth_map(render_array, size, radius)
  *   classifier_code/train_test_scripts/utils/io_utils.py:119-124: z splat, last writer wins.
  * owner_ws (H*W) int32 scratch; depth_out (H,W) f64. */
@@ -137,7 +148,8 @@ int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t 
 
 /* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
  * next n calls of ispa_nn_topk (its filter kernel, the launch that does the MFMA contraction),
- * ispa_project, ispa_project_prune or ispa_flow_splat brackets its dominant kernel with HIP events
+ * ispa_project, ispa_project_prune, ispa_flow_splat or ispa_make_disparity brackets its dominant
+ * kernel with HIP events
  * on the call's stream.  ispa_timing_collect waits for
  * them, writes the elapsed milliseconds of the recorded calls to a HOST array and re-arms the
  * slots.  ispa_timing_enable(0) turns it off and releases the events.  Not thread-safe. */

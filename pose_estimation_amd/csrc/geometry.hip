@@ -7,93 +7,13 @@
 //                       file is compiled with -ffp-contract=off; every fused op is explicit)
 //   pt2render.py:43-55  (A) and classifier_code/.../utils/pt2render.py:43-53 (B) visibility
 #include "common.h"
+#include "geom_device.h"
 
 namespace {
 
+using namespace ispa_geom;
+
 constexpr int kThreads = 256;
-constexpr double kCropSide = 224.0;
-
-struct CropXform {
-    double top, bottom, left, right;  // crop box as doubles (exact: they are int32)
-    double ratio, pad_x, pad_y;
-};
-
-__device__ __forceinline__ CropXform make_crop(const int32_t *c) {
-    CropXform x;
-    x.top = (double)c[0];
-    x.bottom = (double)c[1];
-    x.left = (double)c[2];
-    x.right = (double)c[3];
-    const int y_len = c[1] - c[0];
-    const int x_len = c[3] - c[2];
-    x.pad_x = 0.0;
-    x.pad_y = 0.0;
-    if (y_len >= x_len) {
-        x.ratio = kCropSide / (double)y_len;
-        x.pad_x = (kCropSide - (double)x_len * x.ratio) / 2.0;
-    } else {
-        x.ratio = kCropSide / (double)x_len;
-        x.pad_y = (kCropSide - (double)y_len * x.ratio) / 2.0;
-    }
-    return x;
-}
-
-// Strict crop test on the un-cropped coordinates, then the in-place remap.
-__device__ __forceinline__ bool crop_apply(const CropXform &c, int y_ge_x, int resize, double &u,
-                                           double &v) {
-    const bool inside = (v > c.top) && (v < c.bottom) && (u > c.left) && (u < c.right);
-    u = u - c.left;
-    v = v - c.top;
-    if (resize) {
-        u = u * c.ratio;
-        v = v * c.ratio;
-        if (y_ge_x)
-            u = u + c.pad_x;
-        else
-            v = v + c.pad_y;
-        u = rint(u);
-        v = rint(v);
-    }
-    return inside;
-}
-
-template <int VARIANT>
-__device__ __forceinline__ bool depth_test(double u, double v, double z,
-                                           const float *__restrict__ depth, int H, int W, int ylim,
-                                           int xlim, double relax) {
-    // int() truncation of the already rounded coordinate; NaN/inf fail every comparison.
-    const double yt = trunc(v), xt = trunc(u);
-    if (!(yt > 0.0 && yt < (double)ylim && xt > 0.0 && xt < (double)xlim)) return false;
-    const int y = (int)yt, x = (int)xt;
-    if (VARIANT == ISPA_VIS_A) {
-        const double d = (double)depth[(int64_t)y * W + x];
-        return fabs(z - d) <= relax;
-    } else {
-        const float r32 = (float)relax;
-        float best = __builtin_inff();
-        const int y1 = min(y + 2, H), x1 = min(x + 2, W);
-        for (int yy = y - 1; yy < y1; ++yy)
-            for (int xx = x - 1; xx < x1; ++xx) best = fminf(best, depth[(int64_t)yy * W + xx] + r32);
-        return z <= (double)best;
-    }
-}
-
-__device__ __forceinline__ void project_point(const double *__restrict__ P, double px, double py,
-                                              double pz, double &u, double &v, double &z) {
-    double a[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double acc = P[4 * r + 0] * px;
-        acc = fma(P[4 * r + 1], py, acc);
-        acc = fma(P[4 * r + 2], pz, acc);
-        acc = fma(P[4 * r + 3], 1.0, acc);
-        a[r] = acc;
-    }
-    z = a[2];
-    u = rint(a[0] / a[2]);
-    v = rint(a[1] / a[2]);
-}
-
 // 16-byte streaming store: the projected coordinates are written once and read by later kernels
 // only, so they need not displace anything in the caches.
 typedef double f64x2 __attribute__((ext_vector_type(2)));

@@ -5,6 +5,7 @@
 // Here that is an integer atomicMax of (point index + 1) per pixel followed by a resolve pass,
 // which is order-independent and therefore deterministic.
 #include "common.h"
+#include "geom_device.h"
 
 namespace {
 
@@ -139,6 +140,82 @@ __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *_
             const int64_t i = o - 1;
             val.x = b[i] - a[i];
             val.y = b[n + i] - a[n + i];
+        }
+        out[p] = val;
+    }
+}
+
+// make_disparity in one launch (make_disparity_syn.py:44-68): per (map, half-map band) block,
+// project every point at pose 1, depth-test it against the map's depth image, crop-remap it, and
+// keep per band pixel the highest visible point index (LDS atomicMax); then, per owned pixel,
+// re-project the owning point at both poses and write the flow.  Nothing but the flow map goes to
+// HBM: the projected coordinates of the un-fused path (49 bytes per point and pose) never exist.
+__global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
+    const float *__restrict__ depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+    const int32_t *__restrict__ crop, int crop_per_map, int spread, int band_rows, double *__restrict__ flow) {
+    using namespace ispa_geom;
+    extern __shared__ int owner[];
+    constexpr int side = (int)kCropSide;
+    const int m = blockIdx.y;
+    const int row0 = blockIdx.x * band_rows;
+    const int row1 = min(row0 + band_rows, side);
+    const int npix = (row1 - row0) * side;
+    for (int p = threadIdx.x; p < npix; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    const double *P1 = cams1 + 12 * (int64_t)m;
+    const double *P2 = cams2 + 12 * (int64_t)m;
+    const float *d = depth + (depth_per_map ? (int64_t)m * H * W : 0);
+    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
+    const CropXform cx = make_crop(c);
+    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    constexpr int kBatch = 4;
+    for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
+        double px[kBatch], py[kBatch], pz[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            const int64_t j = i < n ? i : 0;
+            px[e] = pts[3 * j];
+            py[e] = pts[3 * j + 1];
+            pz[e] = pts[3 * j + 2];
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            if (i >= n) continue;
+            double u, v, z;
+            project_point(P1, px[e], py[e], pz[e], u, v, z);
+            if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
+            if (!crop_apply(cx, tall, 1, u, v)) continue;
+            int iu, iv;
+            if (!to_int(u, iu) || !to_int(v, iv)) continue;
+            int y0, y1, x0, x1;
+            py_slice(iv, spread, side, y0, y1);
+            y0 = max(y0, row0);
+            y1 = min(y1, row1);
+            if (y0 >= y1) continue;
+            py_slice(iu, spread, side, x0, x1);
+            const int tag = (int)i + 1;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+        }
+    }
+    __syncthreads();
+    double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
+    for (int p = threadIdx.x; p < npix; p += kBandThreads) {
+        const int o = owner[p];
+        double2 val = make_double2(0.0, 0.0);
+        if (o > 0) {
+            const int64_t i = o - 1;
+            const double x = pts[3 * i], y = pts[3 * i + 1], zz = pts[3 * i + 2];
+            double u1, v1, u2, v2, z;
+            project_point(P1, x, y, zz, u1, v1, z);
+            crop_apply(cx, tall, 1, u1, v1);
+            project_point(P2, x, y, zz, u2, v2, z);
+            crop_apply(cx, tall, 1, u2, v2);
+            val.x = u2 - u1;
+            val.y = v2 - v1;
         }
         out[p] = val;
     }
@@ -315,4 +392,33 @@ extern "C" int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n
     hipLaunchKernelGGL(zbuffer_visibility_kernel, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads),
                        0, (hipStream_t)stream, pt_render, n, depth, H, W, relax, truth);
     return ispa::check_launch("zbuffer_visibility_kernel");
+}
+
+extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const double *cams2,
+                                   int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
+                                   int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
+                                   double *flow, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && n_map >= 0, "bad point count");
+    ISPA_REQUIRE(spread >= 0 && spread <= 64, "bad spread");
+    if (n_map == 0) return ISPA_OK;
+    ISPA_REQUIRE(cams1 && cams2 && depth && crop && flow && (n == 0 || pts), "null pointer");
+    ISPA_REQUIRE(H > 0 && W > 0 && ylim >= 1 && ylim <= H && xlim >= 1 && xlim <= W,
+                 "visibility gate (%d,%d) exceeds the depth map (%d,%d)", ylim, xlim, H, W);
+    ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
+    hipStream_t s = (hipStream_t)stream;
+    const int side = (int)ispa_geom::kCropSide;
+    const int band_rows = kBandPixels / side;
+    const int nbands = (side + band_rows - 1) / band_rows;
+    static bool configured = false;
+    if (!configured) {
+        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&make_disparity_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBandPixels * (int)sizeof(int)));
+        configured = true;
+    }
+    const ispa::TimingSlot timed = ispa::timing_begin(s);
+    hipLaunchKernelGGL(make_disparity_kernel, dim3(nbands, n_map), dim3(kBandThreads),
+                       (size_t)band_rows * side * sizeof(int), s, pts, n, cams1, cams2, depth, depth_per_map, H, W,
+                       ylim, xlim, relax, crop, crop_per_map, spread, band_rows, flow);
+    ispa::timing_end(timed, s);
+    return ispa::check_launch("make_disparity_kernel");
 }

@@ -38,12 +38,14 @@ def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
     return dv.back(flow, as_tensor)
 
 
-def make_disparity_maps(key_3d, params, depth_maps, crop_params):
+def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
     """Body of make_disparity for a batch of renders of ONE model.
 
     key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
     depth_maps (n_map,540,960) f32 (the first pose's depth image, used for both poses as the
     reference does); crop_params (n_map,4).  Only the first pose's truth masks the points.
+    fused=True runs the whole body as one kernel (ispa_make_disparity); fused=False goes through
+    project_prune twice and flow_splat, materialising the projected coordinates like the reference.
     Returns flow (n_map,224,224,2) float64, numpy unless key_3d is a device tensor."""
     as_tensor = dv.is_tensor(key_3d)
     params = np.atleast_2d(np.asarray(params, dtype=np.float64))
@@ -58,6 +60,19 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params):
     if depth.dim() == 2:
         depth = depth[None]
     crops = np.asarray(crop_params).reshape(n_map, 4)
+    if fused:
+        h, w = depth.shape[-2:]
+        if depth.shape[0] not in (1, n_map):
+            raise ValueError("need one depth map per render or a single shared one")
+        c1 = dv.to_dev(cams1, torch.float64)
+        c2 = dv.to_dev(cams2, torch.float64)
+        crop_t = dv.to_dev(crops, torch.int32)
+        flow = dv.empty((n_map, FLOW_SIDE, FLOW_SIDE, 2), torch.float64)
+        _abi.check(_abi.lib.ispa_make_disparity(
+            dv.ptr(pts), pts.shape[0], dv.ptr(c1), dv.ptr(c2), n_map, dv.ptr(depth), 1 if depth.shape[0] > 1 else 0,
+            h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, SPREAD,
+            dv.ptr(flow), dv.stream_ptr()))
+        return dv.back(flow, as_tensor)
     truth1, uv1 = run_proj.project_prune(pts, cams1, depth, crops)
     _, uv2 = run_proj.project_prune(pts, cams2, depth, crops)
     flow = flow_splat(uv1, uv2, truth1)

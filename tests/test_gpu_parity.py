@@ -164,9 +164,11 @@ def test_get_pt_and_grid_indices(pea, golden_disparity, golden_geometry):
 @pytest.mark.parametrize("tag", ["cloud", "mesh", "edge"])
 def test_make_disparity_golden(pea, golden_disparity, tag):
     z = golden_disparity
-    flow = pea.disparity.make_disparity_maps(z[f"{tag}_pts"], z[f"{tag}_params"], z[f"{tag}_depth"], z[f"{tag}_crop"])
-    assert flow.shape == (1, 224, 224, 2) and flow.dtype == np.float64
-    assert np.array_equal(flow[0], z[f"{tag}_flow"])
+    for fused in (True, False):
+        flow = pea.disparity.make_disparity_maps(z[f"{tag}_pts"], z[f"{tag}_params"], z[f"{tag}_depth"],
+                                                 z[f"{tag}_crop"], fused=fused)
+        assert flow.shape == (1, 224, 224, 2) and flow.dtype == np.float64
+        assert np.array_equal(flow[0], z[f"{tag}_flow"])
 
 
 def test_make_disparity_batch_100k(pea):
@@ -182,6 +184,8 @@ def test_make_disparity_batch_100k(pea):
         t = og.depth_visibility_array_a(r, depths[-1])[0]
         crops.append([int(r[1, t].min()) - 3, int(r[1, t].max()) + 3, int(r[0, t].min()) - 3, int(r[0, t].max()) + 3])
     got = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
+    unfused = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops), fused=False)
+    assert np.array_equal(got, unfused)
     for m in range(2):
         want = odisp.make_disparity_core(pts, params[m].tolist(), depths[m], crops[m])
         assert np.array_equal(got[m], want)
