@@ -12,7 +12,6 @@
 //                 the rounding bound of the filter is final, the others are queued
 //   4. exact      float64 re-scoring of every reference for the queued queries, in the channel
 //                 order the CPU oracle uses, so the index order is exact under all inputs
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -159,7 +158,9 @@ struct TagTop1 {
     __device__ __forceinline__ void push(float x, int reg) {
         const float t = __uint_as_float((__float_as_uint(x) & 0xfffffff0u) | (unsigned)reg);
         b = __builtin_amdgcn_fmed3f(a, b, t);
-        a = __builtin_amdgcn_fmed3f(a, t, pinf);               // max(a, t) as one instruction
+        // max(a, t) as ONE two-operand instruction (the compiler would add a canonicalising
+        // v_max in front of fmaxf because t comes out of integer arithmetic)
+        asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(t));
     }
     __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
     __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
@@ -907,7 +908,6 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
     while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
-    if (const char *force = getenv("ISPA_DEV_NSPLIT")) nsplit = atoi(force);   // development knob
     const int64_t cps = (chunks + nsplit - 1) / nsplit;
     p.refs_per_split = cps * chunk_refs;
     p.nsplit = (int)((chunks + cps - 1) / cps);

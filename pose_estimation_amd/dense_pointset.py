@@ -82,7 +82,6 @@ def dense_keypoints_for_renders(anchors, class_name, params, depth_maps, crop_pa
 
     anchors (K,3) as in anchors.txt; params (n,4); depth_maps (n,540,960) f32; crop_params (n,4).
     Returns (n, 2, 10*n_bones) float64 crop coordinates with invisible points zeroed."""
-    from . import _device as dv
     coords = get_additional_coords_keypoint_5(np.asarray(anchors, dtype=np.float64).T, class_name)
     pts3d = np.ascontiguousarray(dense_skeleton(coords, class_name).T)
     params = np.atleast_2d(np.asarray(params, dtype=np.float64))

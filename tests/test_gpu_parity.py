@@ -498,6 +498,23 @@ def test_dense_keypoints(pea, golden_geometry, golden_disparity):
     assert got.shape == (1, 2, 130) and np.array_equal(got[0], want)
 
 
+def test_timing_hooks(pea):
+    import ctypes
+    import torch
+    from pose_estimation_amd import _abi
+    q = torch.randn(2, 32, 256, device="cuda")
+    _abi.check(_abi.lib.ispa_timing_enable(3))
+    for _ in range(4):                                   # the 4th call finds no free slot
+        pea.correspondence.dense_nn(q, q, 1)
+    ms = (ctypes.c_float * 8)()
+    n = ctypes.c_int(0)
+    _abi.check(_abi.lib.ispa_timing_collect(ms, 8, ctypes.byref(n)))
+    assert n.value == 3 and all(0.0 < ms[i] < 100.0 for i in range(3))
+    _abi.check(_abi.lib.ispa_timing_enable(0))
+    _abi.check(_abi.lib.ispa_timing_collect(ms, 8, ctypes.byref(n)))
+    assert n.value == 0
+
+
 def test_errors_are_loud(pea):
     import torch
     from pose_estimation_amd import _abi
