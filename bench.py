@@ -95,16 +95,6 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         return None
 
 
-def synthetic_scene(points, n_views, seed):
-    """Seeded cloud + per-view pose, depth image (z-buffer of the cloud, background 20) and crop."""
-    from oracle import geometry as og, zbuffer as ozb
-    rs = np.random.RandomState(seed)
-    pts = rs.uniform(-0.4, 0.4, (points, 3))
-    params = np.stack([rs.uniform(0, 360, n_views), rs.uniform(-10, 35, n_views), rs.uniform(-5, 5, n_views),
-                       np.full(n_views, 3.0)], axis=1)
-    return pts, params
-
-
 def run_geometry(args, torch, dist, world, rank, dev):
     """Workloads 'project' and 'disparity' (inputs resident in HBM, one GPU's share per rank)."""
     import pose_estimation_amd as pea

@@ -4,7 +4,7 @@
  *
  * The reference is pure Python; it has no FFI layer.  Each entry point below replaces the
  * Python function (or external Caffe layer) cited beside it, and is what a ctypes stub in the
- * reference would bind (INTEGRATION.md shows those stubs).
+ * reference would bind.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the parameter is called host_*;
