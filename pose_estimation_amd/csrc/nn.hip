@@ -659,6 +659,244 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2c. top-1 filter on v_mfma_f32_16x16x32_bf16
+//
+// Same block structure as 2b (256 queries, 4 waves of 64 queries, 64-reference chunks in a
+// 3-slot LDS ring filled by LDS-direct loads, mid-chunk barrier), on the 16x16x32 MFMA shape,
+// which the chip sustains at a higher clock than 32x32x16 on random data.  A wave's 64x32
+// half-step is 2 reference tiles x 4 query tiles of 16x16; a lane owns query column lane&15 of
+// each query tile (4 query streams) and, per tile, the 4 reference rows 4*(lane>>4)+reg.  The
+// tag in the low mantissa bits is tile*4 + reg (3 bits).  LDS reference image: 128-byte rows whose
+// four 32-byte slots are permuted by (row bit 1) | (row bit 3) << 1, which puts the 8 channel rows
+// a 32-lane half reads at once on 8 different 32-byte bank groups.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kT16SubStreams = 4;    // partial result streams per (tile, split): lane >> 4
+
+template <int KS32>
+__global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
+    const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
+    int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
+    int *__restrict__ part_idx) {
+    constexpr int C = 32 * KS32;
+    constexpr int KS = 2 * KS32;                        // 16-channel units, as in bf16_filter_lds_bytes
+    constexpr int kRBuf = C * kRStride;
+    constexpr int kSeg = KS / 2;                        // LDS-direct instructions per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *rbuf = lds;
+    float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);
+
+    int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int qt0 = bid % n_qtiles;
+    bid /= n_qtiles;
+    const int split = bid % nsplit;
+    const int b = bid / nsplit;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wq = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    // transposed-read addressing: every 16-lane group covers the same 16 columns, group g the
+    // channels 8g .. 8g+7 of a 32-channel k-step
+    const int tr_col = 4 * (lane & 3);
+    const int tr_row = 8 * g + ((lane & 15) >> 2);
+
+    const uint16_t *qb = q + (int64_t)b * C * nq;
+    const uint16_t *rb = r + (int64_t)b * C * nr;
+    const float *nhb = rnh + (int64_t)b * nr;
+    const int64_t q0 = (int64_t)qt0 * kBQ;
+    const int64_t rbeg = (int64_t)split * refs_per_split;
+    const int64_t rend = min(rbeg + refs_per_split, nr);
+    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
+
+    // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
+#pragma unroll
+    for (int e = 0; e < 2 * KS; ++e) {
+        const int seg = tid + kBThreads * e;
+        const int row = seg >> 5, col = (seg & 31) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)row * nq + q0 + col);
+        *reinterpret_cast<uint4 *>(lds + row * kQStride + col * 2) = v;
+    }
+    // reference chunk -> LDS slot: lane l lands on row l>>3, physical 16-byte segment l&7 of the
+    // 8 rows its instruction covers and fetches the segment whose 32-byte slot index is XORed
+    // with (row bit 1) | (row bit 3) << 1; row bit 3 is the parity of the instruction index
+    const int wq_u = __builtin_amdgcn_readfirstlane(wq);
+    const uint16_t *st_row = rb + (int64_t)(8 * wq_u * kSeg + (lane >> 3)) * nr;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)rbuf;
+    auto stage = [&](int64_t r0, int slot) {
+#pragma unroll
+        for (int e = 0; e < kSeg; ++e) {
+            const int perm = ((lane >> 4) & 1) | (((wq_u * kSeg + e) & 1) << 1);
+            const int seg = ((((lane & 7) >> 1) ^ perm) << 1) | (lane & 1);
+            const int64_t col = r0 + seg * 8;
+            const uint16_t *src = st_row + (int64_t)e * 8 * nr + (col < rend ? col : 0);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + (wq_u * kSeg + e) * 1024);
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+    float pre_nh = 0.f;
+    bool pre_ok = false;
+    auto fetch_nh = [&](int64_t r0) {
+        pre_ok = r0 + (tid & (kBR - 1)) < rend;
+        pre_nh = nhb[pre_ok ? r0 + (tid & (kBR - 1)) : 0];
+    };
+    auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
+    __syncthreads();
+    bf16x8 bq[4][KS32];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks)
+            bq[qt][ks] = tr_frag(lds + (ks * 32 + tr_row) * kQStride + (wq * 64 + qt * 16 + tr_col) * 2, kQStride);
+    __syncthreads();
+    if (nchunks > 0) {
+        stage(clamp_chunk(0), 0);
+        stage(clamp_chunk(1), 1);
+        fetch_nh(clamp_chunk(0));
+        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        fetch_nh(clamp_chunk(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    TagTop1 best[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) best[qt].init();
+
+    // fragment of reference tile `rt` (16 cells) of half-step `ri`, k-step `ks` of image `rimg`
+    const int rd_perm = ((lane >> 3) & 1) | ((g & 1) << 1);   // (row bit 1) | (row bit 3) << 1 of this lane's rows
+    auto frag = [&](const char *rimg, int ri, int rt, int ks) {
+        const int slot = (ri * 2 + rt) ^ rd_perm;               // 32-byte slot = 16 cells
+        return tr_frag(rimg + (ks * 32 + tr_row) * kRStride + slot * 32 + tr_col * 2, kRStride);
+    };
+    auto load_init = [&](const float *nh, int ri, int rt) {
+        const float4 t = *reinterpret_cast<const float4 *>(nh + ri * 32 + rt * 16 + 4 * g);
+        f32x4 v = {t.x, t.y, t.z, t.w};
+        return v;
+    };
+
+    f32x4 acc_a[2][4], acc_b[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            acc_b[rt][qt] = f32x4{kNegInf, kNegInf, kNegInf, kNegInf};
+            asm volatile("" : "+v"(acc_b[rt][qt]));     // opaque: keeps the loop from being peeled
+        }
+
+    // MFMAs of half-step (`rimg`, `ri`) into `now`; top-list update of `prev` (half-step prev_half)
+    // interleaved one score per MFMA.  a[0..1] hold the two reference-tile fragments of k-step 0 on
+    // entry and those of the next half-step on exit.
+    auto half_step = [&](const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 (&a)[2],
+                         const f32x4 (&init)[2], f32x4 (&now)[2][4], const f32x4 (&prev)[2][4], int prev_half) {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) best[qt].begin_half(prev_half);
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            bf16x8 an[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                an[rt] = ks + 1 < KS32 ? frag(rimg, ri, rt, ks + 1) : frag(next_img, next_ri, rt, 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    now[rt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt], bq[qt][ks],
+                                                                          ks ? now[rt][qt] : init[rt], 0, 0, 0);
+                    // 32 scores per half-step spread over its 8 * KS32 MFMAs
+                    constexpr int per = 4 / KS32 > 0 ? 4 / KS32 : 1;
+                    const int m = (ks * 8 + rt * 4 + qt) * per;     // scores [m, m+per) of the previous half-step
+#pragma unroll
+                    for (int e = 0; e < per; ++e) {
+                        const int sc = m + e;
+                        if (sc < 32) {
+                            const int prt = sc >> 4, pqt = (sc >> 2) & 3, reg = sc & 3;
+                            if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[prt][pqt][reg]));
+                            else best[pqt].push(prev[prt][pqt][reg], prt * 4 + reg);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one MFMA, then its share of the vector work
+                }
+            a[0] = an[0];
+            a[1] = an[1];
+        }
+        if (KS32 == 3) {                                 // 24 MFMAs covered 24 scores: the rest here
+#pragma unroll
+            for (int sc = 24; sc < 32; ++sc)
+                best[(sc >> 2) & 3].push(prev[sc >> 4][(sc >> 2) & 3][sc & 3], (sc >> 4) * 4 + (sc & 3));
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) best[qt].end_half();
+    };
+
+    bf16x8 a[2];
+    f32x4 init_a[2];
+    if (nchunks > 0) {
+        a[0] = frag(rbuf, 0, 0, 0);
+        a[1] = frag(rbuf, 0, 1, 0);
+        init_a[0] = load_init(nhbuf, 0, 0);
+        init_a[1] = load_init(nhbuf, 0, 1);
+    }
+    int slot = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int next_slot = slot == 2 ? 0 : slot + 1;
+        const int after_slot = next_slot == 2 ? 0 : next_slot + 1;
+        const char *rimg = rbuf + slot * kRBuf;
+        const char *next_img = rbuf + next_slot * kRBuf;
+        const f32x4 init_b[2] = {load_init(nhbuf + slot * kBR, 1, 0), load_init(nhbuf + slot * kBR, 1, 1)};
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(rimg, 0, rimg, 1, a, init_a, acc_a, acc_b, chunk * 2 - 1);
+        nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ISPA_ABLATE != 2) stage(clamp_chunk(chunk + 2), after_slot);
+        fetch_nh(clamp_chunk(chunk + 2));
+        init_a[0] = load_init(nhbuf + next_slot * kBR, 0, 0);
+        init_a[1] = load_init(nhbuf + next_slot * kBR, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk * 2);
+        slot = next_slot;
+    }
+    if (nchunks > 0) {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            best[qt].begin_half(nchunks * 2 - 1);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) best[qt].push(acc_b[rt][qt][reg], rt * 4 + reg);
+            best[qt].end_half();
+        }
+    }
+
+    // one partial stream per (split, lane >> 4); finalize merges them
+    const int nparts = nsplit * kT16SubStreams;
+    const int part = split * kT16SubStreams + g;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int64_t qcol = q0 + wq * 64 + qt * 16 + l15;
+        if (qcol >= nq) continue;
+#pragma unroll
+        for (int sl = 0; sl <= 1; ++sl) {
+            const int code = best[qt].code(sl);
+            int ref = -1;
+            if (code >= 0) {                             // code = half-step * 16 + (tile * 4 + reg)
+                const int tag = code & 15;
+                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (tag >> 2) * 16 + 4 * g + (tag & 3));
+            }
+            const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
+            part_val[o] = best[qt].value(sl);
+            part_idx[o] = ref;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3. finalize
 // ---------------------------------------------------------------------------------------------
 template <int K>
@@ -886,6 +1124,7 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
 // ---------------------------------------------------------------------------------------------
 struct Plan {
     bool bf16_mfma;          // native bf16 MFMA filter (else the float32 MFMA filter)
+    bool t16;                // ... on the 16x16x32 shape (top-1 only)
     int tq;                  // queries per block of the chosen filter
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
@@ -899,7 +1138,8 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     p.bf16_mfma = dtype == ISPA_BF16 && C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
     p.tq = p.bf16_mfma ? kBQ : kTQ;
     const int chunk_refs = p.bf16_mfma ? kBR : kTR;
-    const int substreams = p.bf16_mfma ? kBSubStreams : kSubStreams;
+    p.t16 = p.bf16_mfma && k == 1;          // top-1: the 16x16x32 kernel
+    const int substreams = p.t16 ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
     p.ktemplate = k == 1 ? 1 : (k <= 5 ? 5 : kMaxK);
     const int64_t chunks = (nr + chunk_refs - 1) / chunk_refs;
@@ -942,6 +1182,21 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
         configured = true;
     }
     hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
+    return ISPA_OK;
+}
+
+template <int KS32>
+int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
+               int64_t nr, const Plan &p, float *pval, int *pidx) {
+    constexpr int lds_bytes = bf16_filter_lds_bytes<2 * KS32>();
+    static bool configured = false;       // per instantiation
+    if (!configured) {
+        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((nn_filter_bf16_t16_kernel<KS32>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
     return ISPA_OK;
 }
@@ -993,7 +1248,14 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
         const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
         int rc;
-        if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        if (p.t16) {
+            switch (C / 32) {
+                case 1: rc = launch_t16<1>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 2: rc = launch_t16<2>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 3: rc = launch_t16<3>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                default: rc = launch_t16<4>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+            }
+        } else if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         if (rc) return rc;
@@ -1070,6 +1332,7 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
     if (p.bf16_mfma && (((uintptr_t)q | (uintptr_t)r) % 16 != 0)) {
         p = make_plan(ISPA_F32, B, C, nq, nr, k);       // unaligned bf16 input: converting tile loader
         p.bf16_mfma = false;
+        p.t16 = false;
     }
     if (workspace_bytes < p.total)
         return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, p.total);
