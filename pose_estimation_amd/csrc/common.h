@@ -46,6 +46,18 @@ struct TimingSlot {
 TimingSlot timing_begin(hipStream_t stream);
 void timing_end(const TimingSlot &slot, hipStream_t stream);
 
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once per device.
+inline int allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *done_mask) {
+    int dev = 0;
+    ISPA_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(*done_mask & bit)) {
+        ISPA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        *done_mask |= bit;
+    }
+    return ISPA_OK;
+}
+
 inline unsigned blocks_for(int64_t work, int threads, int64_t cap = 1 << 20) {
     int64_t b = (work + threads - 1) / threads;
     if (b < 1) b = 1;

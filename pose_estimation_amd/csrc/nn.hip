@@ -1175,12 +1175,10 @@ template <int KS, int KT>
 int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                 int64_t nr, const Plan &p, float *pval, int *pidx) {
     constexpr int lds_bytes = bf16_filter_lds_bytes<KS>();
-    static bool configured = false;       // per instantiation
-    if (!configured) {
-        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        configured = true;
-    }
+    static unsigned long long configured = 0;       // per instantiation, one bit per device
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT>), lds_bytes,
+                                         &configured))
+        return rc;
     hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
     return ISPA_OK;
@@ -1190,12 +1188,10 @@ template <int KS32>
 int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                int64_t nr, const Plan &p, float *pval, int *pidx) {
     constexpr int lds_bytes = bf16_filter_lds_bytes<2 * KS32>();
-    static bool configured = false;       // per instantiation
-    if (!configured) {
-        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        configured = true;
-    }
+    static unsigned long long configured = 0;       // per instantiation, one bit per device
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32>), lds_bytes,
+                                         &configured))
+        return rc;
     hipLaunchKernelGGL((nn_filter_bf16_t16_kernel<KS32>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
     return ISPA_OK;

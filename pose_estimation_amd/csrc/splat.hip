@@ -315,12 +315,10 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
         const int band_rows = kBandPixels / side;
         const int nbands = (side + band_rows - 1) / band_rows;
         const size_t lds_bytes = (size_t)band_rows * side * sizeof(int);
-        static bool configured = false;
-        if (!configured) {
-            ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&flow_band_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBandPixels * (int)sizeof(int)));
-            configured = true;
-        }
+        static unsigned long long configured = 0;
+        if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&flow_band_kernel),
+                                             kBandPixels * (int)sizeof(int), &configured))
+            return rc;
         const ispa::TimingSlot timed = ispa::timing_begin(s);
         hipLaunchKernelGGL(flow_band_kernel, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, uv1, uv2, truth,
                            n, spread, side, band_rows, flow);
@@ -409,12 +407,10 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
     const int side = (int)ispa_geom::kCropSide;
     const int band_rows = kBandPixels / side;
     const int nbands = (side + band_rows - 1) / band_rows;
-    static bool configured = false;
-    if (!configured) {
-        ISPA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&make_disparity_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBandPixels * (int)sizeof(int)));
-        configured = true;
-    }
+    static unsigned long long configured = 0;
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&make_disparity_kernel),
+                                         kBandPixels * (int)sizeof(int), &configured))
+        return rc;
     const ispa::TimingSlot timed = ispa::timing_begin(s);
     hipLaunchKernelGGL(make_disparity_kernel, dim3(nbands, n_map), dim3(kBandThreads),
                        (size_t)band_rows * side * sizeof(int), s, pts, n, cams1, cams2, depth, depth_per_map, H, W,
