@@ -139,8 +139,9 @@ int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, cons
  * respect to float64 arithmetic on the given inputs (MFMA filter pass + float64 re-scoring of
  * every query whose filter margin is inside the rounding bound).
  * idx (B,k,nq) int32 = flat reference index + index_base (the reference's layer is 1-based);
- * dist (B,k,nq) f32 squared distances; stats (optional, 4 int32): [0] = number of queries that
- * took the float64 path. */
+ * dist (B,k,nq) f32 squared distances; stats (optional, 4 int32): [0] = queries re-scored
+ * against every reference in float64, [1] = queries settled by float64 re-scoring of the few
+ * references that the filter could not separate. */
 size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);
 int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
                  int k, int index_base, float *dist, int32_t *idx, void *workspace,

@@ -60,7 +60,8 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False):
                                      dv.ptr(stats), dv.stream_ptr()))
     out = (dv.back(dist, as_tensor), dv.back(ind, as_tensor))
     if return_stats:
-        out += ({"exact_path_queries": int(stats[0].item())},)
+        st = stats.cpu().tolist()
+        out += ({"exact_path_queries": st[0] + st[1], "full_rescans": st[0], "candidate_rescores": st[1]},)
     return out
 
 

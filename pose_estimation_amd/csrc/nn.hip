@@ -899,15 +899,20 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
 // ---------------------------------------------------------------------------------------------
 // 3. finalize
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restrict__ part_val,
                                                           const int *__restrict__ part_idx, int nparts,
                                                           const float *__restrict__ qnh,
                                                           const int *__restrict__ rmaxbits, int C, int64_t nq,
                                                           int64_t nr, int k_out, int index_base,
-                                                          float err_rel, float *__restrict__ dist,
+                                                          float err_rel, const T *__restrict__ q,
+                                                          const T *__restrict__ r,
+                                                          const double *__restrict__ qq64,
+                                                          const double *__restrict__ rr64,
+                                                          float *__restrict__ dist,
                                                           int *__restrict__ idx, int *__restrict__ amb_count,
-                                                          int *__restrict__ amb_list) {
+                                                          int *__restrict__ amb_list,
+                                                          int *__restrict__ light_count) {
     const int b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
@@ -970,10 +975,66 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             idx[o] = have ? c[s] + index_base : -1;
             dist[o] = have ? qq - 2.f * v[s] : __builtin_inff();
         }
-    } else {
-        const int slot = atomicAdd(amb_count, 1);
-        amb_list[slot] = (int)((int64_t)b * nq + i);   // b*nq+i < 2^31 is checked on the host
+        return;
     }
+    if (K == 1 && v[0] > kAbsent) {
+        // Top-1, margin too small.  Every reference that can still be the exact nearest one scores
+        // at least v[0] - delta.  If in every stream only the stream's best can do that, the
+        // contenders are known by index: re-score just those in float64 (the oracle's channel
+        // order) and keep the smallest (distance, index).  A stream whose runner-up is also in
+        // range may hide contenders, and then the query goes to the full float64 pass.
+        const float lim = v[0] - delta;
+        int cand[8];
+        int nc = 0;
+        bool hidden = false;
+        for (int p = 0; p < nparts; ++p) {
+            const int64_t o = (((int64_t)b * nparts + p) * 2) * nq + i;
+            const float a_s = part_val[o], b_s = part_val[o + nq];
+            if (a_s >= lim) {
+                if (nc < 8) cand[nc++] = part_idx[o];
+                else hidden = true;
+            }
+            if (b_s > kAbsent && b_s >= lim) hidden = true;
+        }
+        for (int e = 0; e < nc; ++e) hidden |= cand[e] < 0;
+        if (!hidden && nc >= 1) {
+            const T *qcol = q + (int64_t)b * C * nq + i;
+            const double qq_d = qq64[(int64_t)b * nq + i];
+            double best_d = __builtin_inf();
+            int best_j = 0x7fffffff;
+            for (int e = 0; e < nc; ++e) {
+                const int j = cand[e];
+                const T *rcol = r + (int64_t)b * C * nr + j;
+                double dot = 0.0;
+                int c0 = 0;
+                for (; c0 + 8 <= C; c0 += 8) {             // 16 loads in flight, then the ordered chain
+                    float qv[8], rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+                        rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+                }
+                for (; c0 < C; ++c0)
+                    dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
+                              (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
+                const double d = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+                if (d < best_d || (d == best_d && j < best_j)) {
+                    best_d = d;
+                    best_j = j;
+                }
+            }
+            const int64_t o = (int64_t)b * nq + i;       // k_out == 1
+            idx[o] = best_j + index_base;
+            dist[o] = (float)best_d;
+            if (light_count) atomicAdd(light_count, 1);
+            return;
+        }
+    }
+    const int slot = atomicAdd(amb_count, 1);
+    amb_list[slot] = (int)((int64_t)b * nq + i);   // b*nq+i < 2^31 is checked on the host
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1281,8 +1342,8 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
 #define ISPA_FINALIZE(KT)                                                                                     \
-    hipLaunchKernelGGL((nn_finalize_kernel<KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
-                       nr, k, index_base, err_rel, dist, idx, count, list)
+    hipLaunchKernelGGL((nn_finalize_kernel<T, KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
+                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, count + 1)
     if (p.ktemplate == 1) ISPA_FINALIZE(1);
     else if (p.ktemplate == 5) ISPA_FINALIZE(5);
     else ISPA_FINALIZE(kMaxK);
@@ -1299,7 +1360,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr, k,
                        index_base, exact_vec_ok, count, list, dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
-    if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, sizeof(int), hipMemcpyDeviceToDevice, s));
+    if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;
 }
 
