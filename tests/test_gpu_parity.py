@@ -60,6 +60,23 @@ def test_projection_100k_bit_exact(pea, golden_geometry):
     assert np.array_equal(np.frombuffer(digest, dtype=np.uint8), z["g2_big_uv_sha256"])
 
 
+def test_projection_half_integer_quotients(pea):
+    """x / z landing exactly on (or one ulp beside) k + 0.5 must round like numpy: half to even."""
+    cam = np.array([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 0, 2.0]])
+    k = np.arange(-2000, 2000, dtype=np.float64)
+    x = 2 * k + 1                                  # x / 2 = k + 0.5 exactly
+    pts = np.stack([x, np.nextafter(x, np.inf), np.nextafter(x, -np.inf)], axis=1)
+    pts = np.concatenate([pts, pts[:, ::-1] * 3.0, np.array([[1e300, -1e300, 0.0], [np.inf, 1.0, 2.0]])])
+    cams = np.stack([cam, cam * np.array([[3.0], [0.5], [1.0]])])
+    cams[1, 2, 3] = 6.0                            # z = 6: quotients k/2 + 1/4 steps, some at .5
+    got = pea.pt2render.get_render_location(pts, cams)
+    for p in range(2):
+        want = cnative.project_fma(pts, cams[p])
+        assert np.array_equal(got[p], want, equal_nan=True)
+        with np.errstate(invalid="ignore", over="ignore"):
+            assert np.array_equal(got[p][:2], og.get_render_location(pts, cams[p])[:2], equal_nan=True)
+
+
 def test_projection_batched_and_ragged(pea, golden_geometry):
     z = golden_geometry
     cams = z["g1_P"][:37]
