@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--workload", choices=["nn", "project", "disparity"], default="nn",
+    ap.add_argument("--workload", choices=["nn", "project", "disparity", "zbuffer"], default="nn",
                     help="nn: dense NN correspondence (the headline); project: 100k points x 3600 poses "
                          "projection + visibility + crop; disparity: make_disparity flow maps of 100k-point renders")
     ap.add_argument("--poses", type=int, default=3600)
@@ -122,6 +122,29 @@ def run_geometry(args, torch, dist, world, rank, dev):
         names = ["project_prune"]
         workload = (f"projection + depth visibility (variant A) + crop remap of a {n}-point model at {P} poses "
                     f"per GPU per step, float64 drop-in layout")
+    elif args.workload == "zbuffer":
+        P = min(args.poses, 720)
+        poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
+        poses = np.resize(poses, (P, 4))
+        cams = torch.from_numpy(pea.pt2render.camera_matrices(poses)).to(dev)
+        out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
+        truth = torch.empty((P, n), dtype=torch.uint8, device=dev)
+        packed = torch.empty((P, 540, 960), dtype=torch.int64, device=dev)
+        zdepth = torch.empty((P, 540, 960), dtype=torch.float32, device=dev)
+
+        def step():
+            _abi.check(_abi.lib.ispa_project(pts.data_ptr(), n, cams.data_ptr(), P, out.data_ptr(), st()))
+            _abi.check(_abi.lib.ispa_zbuffer(out.data_ptr(), n, P, 540, 960, 0, packed.data_ptr(), None,
+                                             zdepth.data_ptr(), st()))
+            _abi.check(_abi.lib.ispa_zbuffer_visibility(out.data_ptr(), n, P, zdepth.data_ptr(), 540, 960, 0.01,
+                                                        truth.data_ptr(), st()))
+        units, unit_name, recs = P, "pose-maps/s", 2
+        # project: points read once + 24 B out per point-pose; z-buffer update kernel: 24 B in and one
+        # 8-byte atomic per point-pose (the memset and resolve launches around it are not in its time)
+        alg_bytes = [24.0 * n + 24.0 * n * P, 32.0 * n * P]
+        names = ["project", "zbuffer"]
+        workload = (f"projection + packed atomicMin z-buffer (540x960) + visibility of a {n}-point model at {P} "
+                    f"poses per GPU per step")
     else:
         M = args.maps
         params = np.stack([rs.uniform(0, 360, M), rs.uniform(-10, 35, M), np.zeros(M), np.full(M, 3.0)], axis=1)
@@ -201,9 +224,10 @@ def run_geometry(args, torch, dist, world, rank, dev):
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
                                                  {"project_prune": "project_prune2_kernel",
-                                                  "flow_band": "flow_band_kernel",
+                                                  "flow_band": "flow_band_kernel", "project": "project2_kernel",
+                                                  "zbuffer": "zbuffer_kernel",
                                                   "make_disparity": "make_disparity_kernel"}[names[dom]],
-                                                 n == 100000 and (args.poses == 3600 if args.workload == "project"
+                                                 n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
                                                                   else args.maps == 256)),
                      "kernel": names[dom],
                      "kernel_ms": round(per[dom], 4), "bytes_per_launch": alg_bytes[dom],
@@ -217,7 +241,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
 def cpu_baseline_geometry(args):
     """The reference's algorithm shape on the host: numpy projection, per-point Python loops for the
     depth test and the splat (oracle restatements of pt2render.py:43-55 and make_disparity_syn.py:65-68)."""
-    from oracle import disparity as odisp, geometry as og
+    from oracle import disparity as odisp, geometry as og, zbuffer as ozb
     n = args.points
     rs = np.random.RandomState(0)
     pts = rs.uniform(-0.4, 0.4, (n, 3))
@@ -227,6 +251,14 @@ def cpu_baseline_geometry(args):
     while True:
         params = [30.0 + done, 10.0, 0.0, 3.0]
         r1 = og.get_3d_to_2d(pts, params)
+        if args.workload == "zbuffer":
+            zdepth = ozb.zbuffer(r1, 540, 960)[2]
+            ozb.zbuffer_visibility(r1, zdepth, 0.01)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or done >= 50:
+                break
+            continue
         t1 = og.depth_visibility_literal(r1, depth, "A")
         c1, _ = og.crop_visibility_array(r1, crop)
         if args.workload == "disparity":
@@ -239,6 +271,10 @@ def cpu_baseline_geometry(args):
         el = time.perf_counter() - t0
         if el >= args.cpu_seconds or done >= 50:
             break
+    if args.workload == "zbuffer":
+        return {"value": round(done / el, 3), "unit": "pose-maps/s", "cores": 1, "kind": "port",
+                "sample": f"{done} poses of {n} points in {el:.1f} s; numpy projection + np.minimum.at z-buffer "
+                          f"(oracle.zbuffer; this mode has no counterpart in the reference)"}
     what = "make_disparity images" if args.workload == "disparity" else "project+prune poses"
     return {"value": round(done / el, 3), "unit": "maps/s" if args.workload == "disparity" else "pose-maps/s",
             "cores": 1, "kind": "port",

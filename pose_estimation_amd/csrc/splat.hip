@@ -368,8 +368,10 @@ extern "C" int ispa_zbuffer(const double *pt_render, int64_t n, int n_pose, int 
     ISPA_HIP(hipMemsetAsync(packed, 0xff, (size_t)total * sizeof(uint64_t), s));
     if (n > 0) {
         ISPA_REQUIRE(pt_render, "null pointer");
+        const ispa::TimingSlot timed = ispa::timing_begin(s);
         hipLaunchKernelGGL(zbuffer_kernel, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads), 0, s,
                            pt_render, n, H, W, radius, (unsigned long long *)packed);
+        ispa::timing_end(timed, s);
         if (int rc = ispa::check_launch("zbuffer_kernel")) return rc;
     }
     if (winner || depth) {
