@@ -58,7 +58,9 @@ inline int allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *
     return ISPA_OK;
 }
 
-inline unsigned blocks_for(int64_t work, int threads, int64_t cap = 1 << 20) {
+// One thread per work item: the grid's x dimension holds up to 2^31 - 1 blocks, far beyond any
+// size the entry points accept, so nothing is ever silently left unprocessed.
+inline unsigned blocks_for(int64_t work, int threads, int64_t cap = 0x7fffffff) {
     int64_t b = (work + threads - 1) / threads;
     if (b < 1) b = 1;
     if (b > cap) b = cap;

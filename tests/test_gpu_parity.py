@@ -240,6 +240,13 @@ def test_zbuffer(pea, golden_geometry):
         assert np.array_equal(got["packed"].view(np.uint64), key)
         vis = pea.zbuffer.visibility(r, got["depth"], relax=0.01)
         assert np.array_equal(vis, ozb.zbuffer_visibility(r, depth, relax=0.01))
+    # many poses: more than 2^20 blocks in the resolve launch
+    import torch
+    big = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(r, (600,) + r.shape))).cuda()
+    got = pea.zbuffer.zbuffer(big, (540, 960), want=("depth",))
+    assert torch.equal(got["depth"][599], got["depth"][0])
+    assert np.array_equal(got["depth"][599].cpu().numpy(), ozb.zbuffer(r, 540, 960)[2])
+    del big, got
     # batched over poses
     rr = np.stack([golden_geometry["g3_near_render"], golden_geometry["g3_std_render"]])
     got = pea.zbuffer.zbuffer(rr, (540, 960))
