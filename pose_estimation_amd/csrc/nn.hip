@@ -1382,7 +1382,7 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
     if (B == 0 || nq == 0) return ISPA_OK;
     ISPA_REQUIRE(C >= 1 && nr >= 1, "need at least one channel and one reference (C=%d, nr=%lld)", C,
                  (long long)nr);
-    ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31), "problem too large");
+    ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31) && B <= 65535, "problem too large");
     ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
     ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16, "unknown dtype %d", dtype);
     Plan p = make_plan(dtype, B, C, nq, nr, k);
