@@ -178,3 +178,19 @@ def nearest_view(view_params, param_np):
     d = normalize_pose_delta(np.asarray(param_np, dtype=np.float64) - np.asarray(view_params))
     d[:, 1:] /= 8.0
     return int(np.argmin(np.linalg.norm(d, axis=1)))
+
+
+def pck_counts(knn_inds_one_based, correspondences, width, radii, downsampling=4):
+    """hard_negative_processing_layer.py:188-190,218-234: per batch item and radius, the number of
+    valid ground-truth correspondences (flag column 4 == 1) whose 1-NN lands within `radius`
+    image pixels of the ground-truth position (columns 2:4)."""
+    knn = np.asarray(knn_inds_one_based)
+    corr = np.asarray(correspondences)
+    xy = ind2coord(knn, width, downsampling)                 # (B, k, n, 2) image coordinates
+    out = np.zeros((len(radii), corr.shape[0]))
+    for n in range(corr.shape[0]):
+        ones = corr[n, :, 4] == 1
+        d = np.sqrt(np.sum((xy[n, 0, ones] - corr[n, ones, 2:4]) ** 2, axis=1))
+        for i, rad in enumerate(radii):
+            out[i, n] = np.sum(d < rad)
+    return out

@@ -2,7 +2,7 @@
 
   dense_nn                 the `KNN` layer contract of ucn_code/nets/train.prototxt:2116-2141
   l2norm                   ucn_code/lib/layers/l2norm_layer.py:18-29
-  ind2coord                ucn_code/lib/layers/hard_negative_processing_layer.py:44-58,188-189
+  ind2coord, pck           ucn_code/lib/layers/hard_negative_processing_layer.py:44-58,188-190,218-234
   CorrelationMapLayer      classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:161-231
   correlation_map_acmm     classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
   get_pt, knn_inds_to_grid classifier_code/train_test_scripts/utils/proxy_renderer.py:50-58 and
@@ -81,6 +81,19 @@ def ind2coord(ind, width, downsampling_factor=4, index_base=1):
     feature stride (hard_negative_processing_layer.py:44-58 after the `- 1` of line 188)."""
     i = np.asarray(ind) - index_base
     return np.stack([i % width, np.floor(i / width)], axis=-1) * downsampling_factor
+
+
+def pck(ind, correspondences, width, radii, downsampling_factor=4, index_base=1):
+    """Hit counts of the 1-NN matches, as HardNegativeProcessingLayer.forward computes them
+    (hard_negative_processing_layer.py:188-190,218-234).
+
+    ind (B,k,n) from dense_nn; correspondences (B,n,5) rows [x1, y1, x2, y2, flag]; a row takes
+    part iff flag == 1; a hit is an image-space distance below the radius.  Returns (len(radii), B)."""
+    xy = ind2coord(ind, width, downsampling_factor, index_base)[:, 0]          # (B,n,2)
+    corr = np.asarray(correspondences)
+    valid = corr[:, :, 4] == 1
+    dist = np.sqrt(np.sum((xy - corr[:, :, 2:4]) ** 2, axis=2))
+    return np.stack([np.sum((dist < r) & valid, axis=1) for r in radii]).astype(np.float64)
 
 
 def resize_bilinear(x, size):

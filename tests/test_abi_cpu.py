@@ -59,6 +59,9 @@ def test_host_helpers_without_gpu():
     assert np.array_equal(correspondence.knn_inds_to_grid(xy), okp.knn_inds_to_grid(xy))
     ind = rs.randint(1, 3137, (2, 1, 50))
     assert np.array_equal(correspondence.ind2coord(ind, 56), okp.ind2coord(ind, 56))
+    corr = np.concatenate([rs.uniform(0, 224, (2, 50, 4)), rs.choice([1.0, 0.0, -1.0], (2, 50, 1))], axis=2)
+    corr[:, :10, 2:4] = okp.ind2coord(ind[:, 0, :10], 56) + 3.0            # planted near-hits
+    assert np.array_equal(correspondence.pck(ind, corr, 56, [10, 20, 40]), okp.pck_counts(ind, corr, 56, [10, 20, 40]))
     stored = np.stack([rs.uniform(0, 360, 500), rs.uniform(-20, 20, 500), rs.uniform(-20, 20, 500)], 1)
     for view in ([0, 10, 0], [359, 0, 0], [120, 10, 0], [181, -3, 4]):
         assert correspondence.nearest_view(view, stored) == okp.nearest_view(view, stored)
