@@ -310,6 +310,10 @@ def test_nn_ties_and_duplicates(pea):
     r2 = np.repeat(r[:, :, :1], 200, axis=2)
     st = _nn_check(pea, q, r2, 1)
     assert st["exact_path_queries"] == 2 * 256
+    st = _nn_check(pea, q, r2, 1, bf16=True)
+    assert st["exact_path_queries"] == 2 * 256
+    _nn_check(pea, q, r, 1, bf16=True)
+    _nn_check(pea, q, r, 5, bf16=True)
 
 
 def test_nn_near_ties_below_rounding(pea):
@@ -324,6 +328,18 @@ def test_nn_near_ties_below_rounding(pea):
     q[0, :, 0] = base
     _nn_check(pea, q, r, 1)
     _nn_check(pea, q, r, 5)
+    # after bfloat16 rounding the near-duplicates collapse into exact ties: lowest index wins
+    _nn_check(pea, q, r, 1, bf16=True)
+    _nn_check(pea, q, r, 5, bf16=True)
+    # references one bfloat16 ulp apart in one channel
+    rb = cnative.round_bf16(r)
+    for t in range(41, 60):
+        rb[0, :, t] = rb[0, :, 40]
+        bits = rb[0, t % 128, t:t + 1].view(np.uint32)
+        bits += np.uint32(0x10000)                       # next bfloat16 away from zero
+    qb = cnative.round_bf16(q)
+    qb[0, :, 0] = rb[0, :, 40]
+    _nn_check(pea, qb, rb, 1, bf16=True)
 
 
 def test_nn_unnormalised_and_index_base(pea):
