@@ -289,6 +289,18 @@ def test_nn_small_ragged(pea, k):
         _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), k)
 
 
+def test_nn_empty_and_single(pea):
+    rs = np.random.RandomState(2)
+    d, i = pea.correspondence.dense_nn(np.zeros((2, 16, 0), np.float32), _unit(rs, (2, 16, 40)), 1)
+    assert d.shape == (2, 1, 0) and i.shape == (2, 1, 0)
+    _nn_check(pea, _unit(rs, (1, 16, 1)), _unit(rs, (1, 16, 1)), 1)
+    _nn_check(pea, _unit(rs, (1, 1, 5)), _unit(rs, (1, 1, 7)), 1)          # one channel: every distance ties or not
+    with pytest.raises(ValueError):
+        pea.correspondence.dense_nn(_unit(rs, (1, 16, 4)), _unit(rs, (1, 8, 4)), 1)
+    with pytest.raises(ValueError):
+        pea.correspondence.dense_nn(_unit(rs, (1, 16, 4)), _unit(rs, (1, 16, 4)), 9)
+
+
 def test_nn_fewer_refs_than_k(pea):
     rs = np.random.RandomState(3)
     _nn_check(pea, _unit(rs, (1, 16, 50)), _unit(rs, (1, 16, 3)), 5)
@@ -399,21 +411,23 @@ def test_nn_bf16_shapes_and_error_model(pea):
             r[:, 1] = -r[:, 0] * (q[:, 0:1].mean() / max(abs(q[:, 1:2].mean()), 1e-3))
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
-        dist, ind = pea.correspondence.dense_nn(qd, rd, 1)
         qr, rr = cnative.round_bf16(q), cnative.round_bf16(r)
-        for i in range(2):
-            _, want_d = cnative.nn_exact(qr[i], rr[i], 1, 1)
-            qn = np.sqrt((qr[i].astype(np.float64) ** 2).sum(0))
-            rmax2 = (rr[i].astype(np.float64) ** 2).sum(0).max()
-            scale = qn * np.sqrt(rmax2) + 0.5 * rmax2
-            bound = 2.0 * 9 * 2 * 2.0 ** -24 * scale          # the library's per-score MFMA model, no safety
-            tag = 2.0 ** -19 * scale                          # 4 tagged mantissa bits
-            err = np.abs(dist[i].cpu().numpy().astype(np.float64) - want_d)[0] / 2.0
-            # the distance also carries float32 roundings of |q|^2 and of the final subtraction
-            slack = 2.0 ** -22 * (qn ** 2 + scale)
-            worst = float(((err - tag - slack) / bound).max())
-            print("bf16 filter error / model bound:", worst)
-            assert worst <= 0.5, worst
+        # k = 1 runs the tagged 16x16x32 kernel, k = 5 the untagged 32x32x16 kernel
+        for k, tagged in ((1, True), (5, False)):
+            dist, ind = pea.correspondence.dense_nn(qd, rd, k)
+            for i in range(2):
+                _, want_d = cnative.nn_exact(qr[i], rr[i], k, 1)
+                qn = np.sqrt((qr[i].astype(np.float64) ** 2).sum(0))
+                rmax2 = (rr[i].astype(np.float64) ** 2).sum(0).max()
+                scale = qn * np.sqrt(rmax2) + 0.5 * rmax2
+                bound = 2.0 * 9 * 2 * 2.0 ** -24 * scale      # the library's per-score MFMA model, no safety
+                tag = 2.0 ** -19 * scale if tagged else 0.0   # 4 tagged mantissa bits
+                err = np.abs(dist[i].cpu().numpy().astype(np.float64) - want_d) / 2.0
+                # the distance also carries the float32 rounding of |q|^2 and of the final subtraction
+                slack = 2.0 ** -23 * (qn ** 2 + scale)
+                worst = float(((err - tag - slack) / bound).max())
+                print(f"bf16 filter error / model bound (k={k}, mix={scale_mix}):", worst)
+                assert worst <= 0.5, worst
 
 
 def test_nn_top5_c256(pea):
