@@ -13,8 +13,28 @@ def timeit(fn, n=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
+# correlation maps at the reference's size (B=8, C=128, 56x56 -> 28x28, K=10)
+def corr_probe():
+    f1 = torch.randn(8, 128, 56, 56, device="cuda"); f1 = f1 / f1.norm(dim=1, keepdim=True)
+    f2 = torch.randn(8, 128, 56, 56, device="cuda"); f2 = f2 / f2.norm(dim=1, keepdim=True)
+    knn = torch.randint(0, 28, (10, 2), device="cuda")
+    mask = (torch.rand(8, 1, 56, 56, device="cuda") > 0.3).float()
+    layer = pea.correspondence.CorrelationMapLayer()
+    ms = timeit(lambda: layer.forward(f1, f2, knn), 20)
+    print(f"corr eccv  B=8 K=10: {ms*1e3:.1f} us  ({8/ms*1e3:.0f} pairs/s)")
+    ms = timeit(lambda: pea.correspondence.correlation_map_acmm(f1, f2, mask), 20)
+    print(f"corr acmm  B=8     : {ms*1e3:.1f} us  ({8/ms*1e3:.0f} pairs/s, {2*784*784*128*8/ms/1e9:.1f} TFLOP/s)")
+    ms = timeit(lambda: pea.correspondence.l2norm(f1), 20)
+    print(f"l2norm     B=8     : {ms*1e3:.1f} us  ({2*f1.numel()*4/ms/1e6:.0f} GB/s)")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "corr":
+    corr_probe()
+    sys.exit(0)
+
 N = 100000
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 3600
+assert P >= 512, "the splat section slices 2 x 256 poses out of the projected array"
 rs = np.random.RandomState(0)
 pts = torch.from_numpy(rs.uniform(-0.4, 0.4, (N, 3))).cuda()
 poses = np.array([[az, el, 0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)[:P]
