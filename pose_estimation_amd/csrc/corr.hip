@@ -112,6 +112,109 @@ __global__ __launch_bounds__(256) void corr_acmm_kernel(const float *__restrict_
     }
 }
 
+// ---- acmm correlation as an MFMA GEMM ------------------------------------------------------------
+// raw[b][p][yx] = relu(sum_c f1[b][c][p] * f2[b][c][yx]): a (cells x C) x (C x cells) product per
+// batch item on v_mfma_f32_32x32x2_f32.  Both operands are channel-major, which is the operand
+// order the instruction wants (lane = cell, k = channel): no transposes.  128 x 128 output tile
+// per 256-thread block, 4 waves as 2 (rows p) x 2 (columns yx) of 64 x 64.  Every block also
+// writes the column sums of squares of its rows to a partial buffer; a second kernel adds the
+// partials in a fixed order (deterministic), normalises and applies the pooled mask.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kCT = 128;   // tile edge
+constexpr int kCK = 16;    // channels per LDS stage
+
+__global__ __launch_bounds__(256) void corr_acmm_gemm_kernel(const float *__restrict__ f1r,
+                                                             const float *__restrict__ f2r, int C, int cells,
+                                                             float *__restrict__ out,
+                                                             float *__restrict__ colsq /* (B, 2*ptiles, cells) */) {
+    __shared__ __attribute__((aligned(16))) float As[kCK][kCT];   // f1 tile: rows p
+    __shared__ __attribute__((aligned(16))) float Bs[kCK][kCT];   // f2 tile: columns yx
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.y * kCT, x0 = blockIdx.x * kCT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const float *a = f1r + (int64_t)b * C * cells;
+    const float *bb = f2r + (int64_t)b * C * cells;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += kCK) {
+        __syncthreads();
+        // 16 rows x 128 columns per tile = 512 groups of 4 floats, 2 per thread; cells % 4 == 0 is
+        // checked on the host, so a group is entirely inside or outside the map
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int g = threadIdx.x + 256 * e;
+            const int row = g >> 5, col = (g & 31) * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (c0 + row < C) {
+                if (p0 + col < cells) va = *reinterpret_cast<const float4 *>(a + (int64_t)(c0 + row) * cells + p0 + col);
+                if (x0 + col < cells) vb = *reinterpret_cast<const float4 *>(bb + (int64_t)(c0 + row) * cells + x0 + col);
+            }
+            *reinterpret_cast<float4 *>(&As[row][col]) = va;
+            *reinterpret_cast<float4 *>(&Bs[row][col]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kCK; kk += 2) {
+            const float a0 = As[kk + h][wr * 64 + l31], a1 = As[kk + h][wr * 64 + 32 + l31];
+            const float b0 = Bs[kk + h][wc * 64 + l31], b1 = Bs[kk + h][wc * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // this lane owns column x0 + wc*64 + j*32 + l31 and rows p0 + wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*h
+    float *o = out + (int64_t)b * cells * cells;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = x0 + wc * 64 + j * 32 + l31;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fmaxf(acc[i][j][r], 0.f);
+                if (row < cells && col < cells) {
+                    o[(int64_t)row * cells + col] = v;
+                    sq = fmaf(v, v, sq);
+                }
+            }
+        sq += __shfl_xor(sq, 32);                 // the two lane halves hold the other rows of the column
+        if (h == 0 && col < cells)
+            colsq[((int64_t)b * 2 * gridDim.y + 2 * blockIdx.y + wr) * cells + col] = sq;
+    }
+}
+
+__global__ __launch_bounds__(256) void corr_acmm_scale_kernel(float *__restrict__ out, const float *__restrict__ colsq,
+                                                              int nparts, const float *__restrict__ mask, int grid,
+                                                              int H, int W) {
+    const int b = blockIdx.z;
+    const int cells = grid * grid;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cells) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += colsq[((int64_t)b * nparts + p) * cells + col];
+    const float norm = sqrtf(s);
+    const int y = col / grid, x = col % grid;
+    const float *m = mask + (int64_t)b * H * W;
+    float mv = -__builtin_inff();                 // max_pool2d(mask, 2, 2, ceil_mode=True)
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int yy = 2 * y + dy, xx = 2 * x + dx;
+            if (yy < H && xx < W) mv = fmaxf(mv, m[yy * W + xx]);
+        }
+    float *o = out + (int64_t)b * cells * cells + col;
+    for (int p = blockIdx.y; p < cells; p += gridDim.y) o[(int64_t)p * cells] = o[(int64_t)p * cells] / norm * mv;
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ x, int C, int64_t hw,
                                                      float *__restrict__ out) {
     const int b = blockIdx.y;
@@ -176,6 +279,18 @@ extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float 
     float *f1r = workspace, *f2r = workspace + (int64_t)B * C * cells;
     if (int rc = launch_resize(f1, (int64_t)B * C, H, W, grid, grid, f1r, s)) return rc;
     if (int rc = launch_resize(f2, (int64_t)B * C, H, W, grid, grid, f2r, s)) return rc;
+    if (cells % 4 == 0) {
+        // MFMA product + deterministic column normalisation; the column partials live behind the two
+        // resized maps in the workspace
+        const int ptiles = (cells + kCT - 1) / kCT;
+        float *colsq = workspace + 2 * (int64_t)B * C * cells;
+        hipLaunchKernelGGL(corr_acmm_gemm_kernel, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells, out,
+                           colsq);
+        if (int rc = ispa::check_launch("corr_acmm_gemm_kernel")) return rc;
+        hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, 16, B), dim3(256), 0, s, out, colsq,
+                           2 * ptiles, mask, grid, H, W);
+        return ispa::check_launch("corr_acmm_scale_kernel");
+    }
     hipLaunchKernelGGL(corr_acmm_kernel, dim3((cells + 63) / 64, B), dim3(256), 0, s, f1r, f2r, mask, C, grid, H, W,
                        out);
     return ispa::check_launch("corr_acmm_kernel");
