@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--workload", choices=["nn", "project", "disparity", "zbuffer"], default="nn",
+    ap.add_argument("--workload", choices=["nn", "project", "disparity", "zbuffer", "corr"], default="nn",
                     help="nn: dense NN correspondence (the headline); project: 100k points x 3600 poses "
                          "projection + visibility + crop; disparity: make_disparity flow maps of 100k-point renders")
     ap.add_argument("--poses", type=int, default=3600)
@@ -122,6 +122,30 @@ def run_geometry(args, torch, dist, world, rank, dev):
         names = ["project_prune"]
         workload = (f"projection + depth visibility (variant A) + crop remap of a {n}-point model at {P} poses "
                     f"per GPU per step, float64 drop-in layout")
+    elif args.workload == "corr":
+        from pose_estimation_amd import correspondence as co
+        bsz, views, kpts = 8, 3, 10                     # multi_view_configs/train_config.py: batch 8, 3 views
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+
+        def unit(*shape):
+            x = torch.randn(*shape, device=dev, generator=g)
+            return (x / x.norm(dim=1, keepdim=True)).contiguous()
+        f_real = unit(bsz, 128, 56, 56)
+        f_tmpl = [unit(bsz, 128, 56, 56) for _ in range(views)]
+        knn = [torch.randint(0, 28, (kpts, 2), device=dev, generator=g) for _ in range(views)]
+        mask = (torch.rand(bsz, 1, 56, 56, device=dev, generator=g) > 0.3).float()
+        layer = co.CorrelationMapLayer()
+
+        def step():
+            for v in range(views):                      # eccv_net.Net.forward: one keypoint map set per view
+                layer.forward(f_real, f_tmpl[v], knn[v])
+            co.correlation_map_acmm(f_real, f_tmpl[0], mask)     # net_final_old: one dense map per pair
+        units, unit_name, recs = bsz, "pairs/s", views + 1
+        cells = 28 * 28
+        alg_bytes = [4.0 * bsz * 128 * cells + 4.0 * bsz * kpts * cells] * views + [2.0 * cells * cells * 128 * bsz]
+        names = ["corr_eccv"] * views + ["corr_acmm_gemm"]
+        workload = (f"correlation maps at the reference's size: {views} x eccv keypoint maps (K={kpts}) + 1 x acmm "
+                    f"dense map for {bsz} pairs of 128x56x56 features per GPU per step")
     elif args.workload == "zbuffer":
         P = min(args.poses, 720)
         poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
@@ -214,24 +238,31 @@ def run_geometry(args, torch, dist, world, rank, dev):
     if rank != 0:
         return
     achieved = alg_bytes[dom] / (per[dom] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4)}
+    if names[dom] == "corr_acmm_gemm":                  # alg_bytes holds FLOP for this kernel
+        tf = alg_bytes[dom] / (per[dom] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_PEAK_TFLOPS["f32"], 4)}
     out_json = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
         "value": round(units * world * args.steps / elapsed, 2), "unit": unit_name, "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.workload == "corr" else "f64", "data": "synthetic",
         "config": {"workload": workload, "points": n},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
+        "roofline": dict(roof,
+                     traffic=measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
                                                  {"project_prune": "project_prune2_kernel",
                                                   "flow_band": "flow_band_kernel", "project": "project2_kernel",
-                                                  "zbuffer": "zbuffer_kernel",
+                                                  "zbuffer": "zbuffer_kernel", "corr_eccv": "corr_eccv_kernel",
+                                                  "corr_acmm_gemm": "corr_acmm_gemm_kernel",
                                                   "make_disparity": "make_disparity_kernel"}[names[dom]],
-                                                 n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
-                                                                  else args.maps == 256)),
-                     "kernel": names[dom],
-                     "kernel_ms": round(per[dom], 4), "bytes_per_launch": alg_bytes[dom],
-                     "all_kernels_ms": {f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}},
+                                                 args.workload == "corr" or (n == 100000 and (
+                                                     args.poses == 3600 if args.workload in ("project", "zbuffer")
+                                                     else args.maps == 256))),
+                     kernel=names[dom], kernel_ms=round(per[dom], 4), work_per_launch=alg_bytes[dom],
+                     all_kernels_ms={f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}),
     }
     if not args.no_cpu_baseline and world == 1:
         out_json["cpu_baseline"] = cpu_baseline_geometry(args)
@@ -242,6 +273,26 @@ def cpu_baseline_geometry(args):
     """The reference's algorithm shape on the host: numpy projection, per-point Python loops for the
     depth test and the splat (oracle restatements of pt2render.py:43-55 and make_disparity_syn.py:65-68)."""
     from oracle import disparity as odisp, geometry as og, zbuffer as ozb
+    if args.workload == "corr":
+        from oracle import correlation as ocorr
+        rs = np.random.RandomState(0)
+        f1 = rs.randn(8, 128, 56, 56).astype(np.float32)
+        f2 = rs.randn(8, 128, 56, 56).astype(np.float32)
+        knn = rs.randint(0, 28, (10, 2))
+        mask = (rs.rand(8, 1, 56, 56) > 0.3).astype(np.float32)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(3):
+                ocorr.correlation_map_eccv(f1, f2, knn)
+            ocorr.correlation_map_acmm(f1, f2, mask)
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or done >= 50:
+                break
+        return {"value": round(8 * done / el, 3), "unit": "pairs/s", "cores": os.cpu_count() or 1, "kind": "port",
+                "sample": f"{done} steps (3 x eccv K=10 + 1 x acmm, B=8) in {el:.1f} s; numpy einsum restatement "
+                          f"(oracle.correlation), which contracts only the K needed rows unlike the reference's "
+                          f"5-D broadcast"}
     n = args.points
     rs = np.random.RandomState(0)
     pts = rs.uniform(-0.4, 0.4, (n, 3))

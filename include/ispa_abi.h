@@ -149,7 +149,8 @@ int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t 
 
 /* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
  * next n calls of ispa_nn_topk (its filter kernel, the launch that does the MFMA contraction),
- * ispa_project, ispa_project_prune, ispa_flow_splat, ispa_make_disparity or ispa_zbuffer brackets its dominant
+ * ispa_project, ispa_project_prune, ispa_flow_splat, ispa_make_disparity, ispa_zbuffer or
+ * ispa_corr_map_eccv / ispa_corr_map_acmm brackets its dominant
  * kernel with HIP events
  * on the call's stream.  ispa_timing_collect waits for
  * them, writes the elapsed milliseconds of the recorded calls to a HOST array and re-arms the

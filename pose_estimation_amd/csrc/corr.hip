@@ -60,7 +60,16 @@ __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict_
     float esum = 0.f;
     for (int p = threadIdx.x; p < cells; p += 256) {
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(tmpl[c], f1r[base + (int64_t)c * cells + p], acc);
+        const float *col = f1r + base + p;
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {                 // 8 loads in flight, then the ordered chain
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * cells];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(tmpl[c + u], v[u], acc);
+        }
+        for (; c < C; ++c) acc = fmaf(tmpl[c], col[(int64_t)c * cells], acc);
         acc = fmaxf(acc, 0.f);
         o[p] = acc;
         esum += expf(acc);
@@ -261,8 +270,10 @@ extern "C" int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_
     float *f1r = workspace, *f2r = workspace + (int64_t)B * C * grid * grid;
     if (int rc = launch_resize(f1, (int64_t)B * C, H, W, grid, grid, f1r, s)) return rc;
     if (int rc = launch_resize(f2, (int64_t)B * C, H, W, grid, grid, f2r, s)) return rc;
+    const ispa::TimingSlot timed = ispa::timing_begin(s);
     hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, B), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, C, grid,
                        K, out);
+    ispa::timing_end(timed, s);
     return ispa::check_launch("corr_eccv_kernel");
 }
 
@@ -284,8 +295,10 @@ extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float 
         // resized maps in the workspace
         const int ptiles = (cells + kCT - 1) / kCT;
         float *colsq = workspace + 2 * (int64_t)B * C * cells;
+        const ispa::TimingSlot timed = ispa::timing_begin(s);
         hipLaunchKernelGGL(corr_acmm_gemm_kernel, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells, out,
                            colsq);
+        ispa::timing_end(timed, s);
         if (int rc = ispa::check_launch("corr_acmm_gemm_kernel")) return rc;
         hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, 16, B), dim3(256), 0, s, out, colsq,
                            2 * ptiles, mask, grid, H, W);
