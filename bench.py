@@ -48,6 +48,7 @@ def parse():
                     help="disparity workload through project_prune x2 + flow_splat instead of the fused kernel")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step result all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the bfloat16 side measurement of the f32 run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -403,6 +404,42 @@ def main():
     _abi.check(_abi.lib.ispa_timing_enable(0))
     filt_ms = float(np.mean(ms[:cnt.value])) if cnt.value else float("nan")
 
+    # Not part of `value`: the same batch through the bfloat16 path (inputs rounded to bfloat16, results
+    # exact for those inputs), reported beside the float32 headline.
+    extra = {}
+    if args.dtype == "f32" and not args.no_extra:
+        q16, r16 = q.to(torch.bfloat16), r.to(torch.bfloat16)
+        for _ in range(2):
+            pea.correspondence.dense_nn(q16, r16, args.k)
+        n16 = 10
+        _abi.check(_abi.lib.ispa_timing_enable(n16))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n16):
+            pea.correspondence.dense_nn(q16, r16, args.k)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el16 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el16], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el16 = float(t.item())
+        ms16 = (ctypes.c_float * n16)()
+        cnt16 = ctypes.c_int(0)
+        _abi.check(_abi.lib.ispa_timing_collect(ms16, n16, ctypes.byref(cnt16)))
+        _abi.check(_abi.lib.ispa_timing_enable(0))
+        k16 = float(np.mean(ms16[:cnt16.value])) if cnt16.value else float("nan")
+        tf16 = 2.0 * n * n * c * b / (k16 * 1e-3) / 1e12
+        extra["bf16"] = {"value": round(b * world * n16 / el16, 2), "unit": "maps/s", "steps": n16,
+                         "ms_per_step": round(el16 / n16 * 1e3, 4), "result_allgather": False,
+                         "roofline": {"bound": "mfma", "achieved": round(tf16, 2), "peak": MFMA_PEAK_TFLOPS["bf16"],
+                                      "unit": "TFLOP/s", "frac": round(tf16 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                                      "kernel": "nn_filter", "kernel_ms": round(k16, 4)}}
+        del q16, r16
+
     if rank == 0:
         pairs_total = b * world * args.steps
         flop_per_pair = 2.0 * n * n * c                          # GEMM term of the distance stage
@@ -433,6 +470,8 @@ def main():
                          "kernel": "nn_filter", "kernel_ms": round(filt_ms, 4),
                          "flop_per_launch": flop_per_pair * b},
         }
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, c, args.k, args.cpu_seconds)
         print(json.dumps(out))
