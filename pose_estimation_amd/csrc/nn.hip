@@ -1033,6 +1033,82 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             return;
         }
     }
+    if (K > 1 && k_out <= K && v[k_out - 1] > kAbsent) {
+        // Top-k, some margin too small.  Every reference that can be among the exact k nearest scores
+        // at least lim = v[k-1] - delta.  The merged list holds every kept entry above its last
+        // value, and a stream can hide an unkept reference above lim only if its own last kept score
+        // reaches lim.  If neither the merged list nor any stream ends above lim, the contenders are
+        // the merged entries >= lim, all known by index: re-score them in float64 and sort.
+        const float lim = v[k_out - 1] - delta;
+        bool hidden = v[K] > kAbsent && !(v[K] < lim);
+        for (int p = 0; p < nparts && !hidden; ++p) {
+            const float last = part_val[(((int64_t)b * nparts + p) * (K + 1) + K) * nq + i];
+            if (last != last || (last > kAbsent && last >= lim)) hidden = true;
+        }
+        int nc = 0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (v[s] != v[s]) hidden = true;
+            if (v[s] > kAbsent && v[s] >= lim) {
+                if (c[s] < 0) hidden = true;
+                nc = s + 1;                              // the list is sorted: contenders are a prefix
+            }
+        }
+        if (!hidden && nc >= k_out) {
+            const T *qcol = q + (int64_t)b * C * nq + i;
+            const double qq_d = qq64[(int64_t)b * nq + i];
+            double cd[K];
+            int cj[K];
+#pragma unroll
+            for (int e = 0; e < K; ++e) {
+                cd[e] = __builtin_inf();
+                cj[e] = 0x7fffffff;
+                if (e < nc) {
+                    const int j = c[e];
+                    const T *rcol = r + (int64_t)b * C * nr + j;
+                    double dot = 0.0;
+                    int c0 = 0;
+                    for (; c0 + 8 <= C; c0 += 8) {
+                        float qv[8], rv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+                            rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+                    }
+                    for (; c0 < C; ++c0)
+                        dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
+                                  (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
+                    cd[e] = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+                    cj[e] = j;
+                }
+            }
+            // order the contenders by (distance, index): K is small, a full exchange sort is cheap
+#pragma unroll
+            for (int a = 0; a < K; ++a)
+#pragma unroll
+                for (int e = a + 1; e < K; ++e) {
+                    const bool sw = cd[e] < cd[a] || (cd[e] == cd[a] && cj[e] < cj[a]);
+                    const double td = sw ? cd[a] : cd[e];
+                    const int tj = sw ? cj[a] : cj[e];
+                    cd[a] = sw ? cd[e] : cd[a];
+                    cj[a] = sw ? cj[e] : cj[a];
+                    cd[e] = td;
+                    cj[e] = tj;
+                }
+#pragma unroll
+            for (int s = 0; s < K; ++s)
+                if (s < k_out) {
+                    const int64_t o = ((int64_t)b * k_out + s) * nq + i;
+                    idx[o] = cj[s] + index_base;
+                    dist[o] = (float)cd[s];
+                }
+            if (light_count) atomicAdd(light_count, 1);
+            return;
+        }
+    }
     const int slot = atomicAdd(amb_count, 1);
     amb_list[slot] = (int)((int64_t)b * nq + i);   // b*nq+i < 2^31 is checked on the host
 }
