@@ -4,6 +4,8 @@ Bars: integer / boolean / index results bit-exact; float64 z and flow values bit
 the oracle's fixed-order twin and <= 1e-12 relative against the imported reference's numpy;
 float32 distances and correlation maps within 1e-4 relative (tolerances written at each assert).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -210,6 +212,48 @@ def test_make_disparity_batch_100k(pea):
     # determinism of the atomic owner pass: two more runs give the same bytes
     again = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
     assert np.array_equal(got, again)
+
+
+def test_script_entry_points_on_a_data_tree(pea, tmp_path, golden_geometry):
+    """make_disparity / make_dense_keypoints over a directory laid out like the reference's ../data."""
+    gv = pea.global_variables
+    saved = {k: getattr(gv, k) for k in ("anchor_loc", "depth_loc", "syn_disparity_loc", "syn_dense_keypoint_loc",
+                                         "g_save_file_location_final", "sample_points_loc", "g_shapenet_root_folder")}
+    try:
+        for k in saved:
+            setattr(gv, k, str(tmp_path / k))
+            (tmp_path / k).mkdir()
+        model, synset = gv.syn_template["chair"]
+        rs = np.random.RandomState(3)
+        pts = rs.uniform(-0.35, 0.35, (20000, 3))
+        np.save(tmp_path / "sample_points_loc" / f"{synset}_{model}.npy", pts)
+        anchors = golden_geometry["g2_anchor_chair"]
+        np.savetxt(tmp_path / "anchor_loc" / f"{model}.txt", anchors, delimiter=" ")
+        renders = []
+        for az, el, tilt in ((30.0, 10.0, 0.0), (211.5, 25.25, -4.0), (95.0, -5.0, 3.5)):
+            d = {"model_type": synset, "model_md5": model, "azimuth": az, "elevation": el, "tilt": tilt, "rho": 2.5,
+                 "crop_params": [60, 470, 250, 720]}
+            name = os.path.basename(pea.io_utils.get_final_file_name(d))
+            r = og.get_3d_to_2d(np.concatenate([pts, anchors]), [az, el, tilt, 2.5])
+            depth = ozb.zbuffer(r, 540, 960, radius=2)[2]
+            depth[~np.isfinite(depth)] = 20.0
+            depth = depth.astype(np.float32)
+            (tmp_path / "g_save_file_location_final" / name).write_bytes(b"")
+            np.save(tmp_path / "depth_loc" / (pea.io_utils.img_to_depth_file(name) + ".npy"), depth)
+            renders.append((name, d, depth))
+        (tmp_path / "g_save_file_location_final" / "04256520_other_a0@000_e0@000_t0@000_d2@000_1_2_3_4_.jpg").write_bytes(b"")
+        assert pea.make_disparity_syn.make_disparity("chair") == 3
+        assert pea.make_dense_pointset_syn.make_dense_keypoints("chair") == 3
+        for name, d, depth in renders:
+            params = [d["azimuth"], d["elevation"], d["tilt"], d["rho"]]
+            flow = np.load(tmp_path / "syn_disparity_loc" / (name.split(".")[0] + ".npy"))
+            assert flow.dtype == np.float64 and flow.shape == (224, 224, 2)
+            assert np.array_equal(flow, odisp.make_disparity_core(pts, params, depth, d["crop_params"]))
+            keys = np.load(tmp_path / "syn_dense_keypoint_loc" / (name.split(".")[0] + ".npy"))
+            assert np.array_equal(keys, okp.make_dense_keypoints_core(anchors, "chair", params, depth, d["crop_params"]))
+    finally:
+        for k, v in saved.items():
+            setattr(gv, k, v)
 
 
 def test_flow_splat_slice_semantics(pea):
