@@ -38,7 +38,8 @@ typedef enum ispa_status {
 } ispa_status;
 
 enum { ISPA_VIS_A = 0, ISPA_VIS_B = 1 };          /* depth-visibility variants         */
-enum { ISPA_F32 = 0, ISPA_BF16 = 1 };             /* feature dtypes for ispa_nn_topk   */
+/* feature dtypes for ispa_nn_topk; ISPA_F32_SPLIT = float32 inputs, split-bfloat16 MFMA filter */
+enum { ISPA_F32 = 0, ISPA_BF16 = 1, ISPA_F32_SPLIT = 2 };
 
 int ispa_abi_version(void);
 const char *ispa_last_error(void);
@@ -141,8 +142,13 @@ int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, cons
  * idx (B,k,nq) int32 = flat reference index + index_base (the reference's layer is 1-based);
  * dist (B,k,nq) f32 squared distances; stats (optional, 4 int32): [0] = queries re-scored
  * against every reference in float64, [1] = queries settled by float64 re-scoring of the few
- * references that the filter could not separate. */
-size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);
+ * references that the filter could not separate.
+ * ISPA_F32_SPLIT takes the same float32 arrays as ISPA_F32 and returns the same exact index order;
+ * its filter pass runs the contraction on bfloat16 MFMAs over a hi/lo split of the inputs (top-1,
+ * C a multiple of 32 up to 128, cell counts multiples of 8; other requests run as ISPA_F32) and
+ * needs a larger workspace: ask ispa_nn_workspace_bytes_for. */
+size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);     /* ISPA_F32 / ISPA_BF16 */
+size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k);
 int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
                  int k, int index_base, float *dist, int32_t *idx, void *workspace,
                  size_t workspace_bytes, int32_t *stats, void *stream);

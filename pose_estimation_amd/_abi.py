@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ISPA_HIP_LIBRARY") or os.path.join(_HERE, "libispa_hi
 
 ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1
-F32, BF16 = 0, 1
+F32, BF16, F32_SPLIT = 0, 1, 2
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -34,6 +34,7 @@ SIGNATURES = {
     "ispa_zbuffer": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "ispa_zbuffer_visibility": (_i, [_p, _i64, _i, _p, _i, _i, _d, _p, _p]),
     "ispa_nn_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i]),
+    "ispa_nn_workspace_bytes_for": (_sz, [_i, _i, _i, _i64, _i64, _i]),
     "ispa_nn_topk": (_i, [_p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "ispa_timing_enable": (_i, [_i]),
     "ispa_timing_collect": (_i, [_p, _i, _p]),

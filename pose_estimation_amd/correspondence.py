@@ -27,13 +27,18 @@ def _workspace(nbytes):
     return ws
 
 
-def dense_nn(query, ref, k=1, index_base=1, return_stats=False):
+def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native"):
     """k nearest reference cells (squared L2) for every query column.
 
     query (B,C,Hq,Wq) or (B,C,n); ref (B,C,H,W) or (B,C,nr); float32, or bfloat16 torch tensors.
     Returns dist (B,k,n) float32 and ind (B,k,n) int32 with ind = y*W + x + index_base (the
     reference's layer is 1-based), neighbours ordered by (distance, index).  The index order is
-    exact with respect to float64 arithmetic on the given inputs."""
+    exact with respect to float64 arithmetic on the given inputs.
+
+    filter="split" (float32 inputs, k=1): the filter pass contracts a bfloat16 hi/lo split of the
+    inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones."""
+    if filter not in ("native", "split"):
+        raise ValueError("filter must be 'native' or 'split'")
     as_tensor = dv.is_tensor(query)
     bf16 = as_tensor and query.dtype == torch.bfloat16
     tdt = torch.bfloat16 if bf16 else torch.float32
@@ -50,12 +55,13 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False):
     dist = dv.empty((b, k, nq), torch.float32)
     ind = dv.empty((b, k, nq), torch.int32)
     stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
-    key = (b, c, nq, nr, k)
+    code = _abi.BF16 if bf16 else (_abi.F32_SPLIT if filter == "split" else _abi.F32)
+    key = (code, b, c, nq, nr, k)
     need = _ws_bytes.get(key)
     if need is None:
-        need = _ws_bytes[key] = _abi.lib.ispa_nn_workspace_bytes(b, c, nq, nr, k)
+        need = _ws_bytes[key] = _abi.lib.ispa_nn_workspace_bytes_for(code, b, c, nq, nr, k)
     ws = _workspace(max(need, 256))
-    _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), _abi.BF16 if bf16 else _abi.F32, b, c, nq, nr, k,
+    _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), code, b, c, nq, nr, k,
                                      int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
                                      dv.ptr(stats), dv.stream_ptr()))
     out = (dv.back(dist, as_tensor), dv.back(ind, as_tensor))

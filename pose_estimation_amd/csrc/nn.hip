@@ -626,6 +626,7 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_kernel(
         half_step(rimg, 1, next_img, 0, a0, a1, init_b, acc_b, acc_a, chunk * 2);
         slot = next_slot;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
@@ -862,6 +863,7 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
         half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk * 2);
         slot = next_slot;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -886,6 +888,300 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
             const int code = best[qt].code(sl);
             int ref = -1;
             if (code >= 0) {                             // code = half-step * 16 + (tile * 4 + reg)
+                const int tag = code & 15;
+                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (tag >> 2) * 16 + 4 * g + (tag & 3));
+            }
+            const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
+            part_val[o] = best[qt].value(sl);
+            part_idx[o] = ref;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2d. float32 inputs through a split-bfloat16 filter (top-1)
+//
+// x = hi + lo + e with hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-16 |x|.  The filter score is
+// r_hi.q_hi + r_lo.q_hi + r_hi.q_lo - |r|^2/2 on the 16x16x32 bf16 MFMA: three MFMAs per tile and
+// k-step at the bf16 rate instead of float32 MFMAs at 1/16 of it.  What is dropped (r_lo.q_lo and
+// the e terms) is at most 3 * 2^-16 |q||r|, which goes into the margin test; queries inside the
+// margin are re-scored in float64 on the ORIGINAL float32 inputs like everywhere else, so the
+// results are the exact ones for the float32 inputs.
+//
+// nn_split_norms_kernel writes hi / lo (and the norms) in one pass over the float32 map.
+// nn_filter_split_kernel: 256-thread block = 128 queries (wave w: 32 queries = 2 tiles of 16),
+// 64-reference chunks whose hi and lo images sit in a 2-slot LDS ring filled by LDS-direct loads;
+// the same 32-byte-slot permutation as in 2c keeps the transposed reads conflict-free.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void nn_split_norms_kernel(const float *__restrict__ x, int C, int64_t n,
+                                                             uint16_t *__restrict__ hi, uint16_t *__restrict__ lo,
+                                                             float *__restrict__ nh, double *__restrict__ sq64,
+                                                             int *__restrict__ maxbits) {
+    const int b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (j < n) {
+        const int64_t base = (int64_t)b * C * n + j;
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[base + (int64_t)(c + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s = fma((double)v[u], (double)v[u], s);
+                const uint16_t h = bf16_rne(v[u]);
+                hi[base + (int64_t)(c + u) * n] = h;
+                lo[base + (int64_t)(c + u) * n] = bf16_rne(v[u] - __uint_as_float((uint32_t)h << 16));
+            }
+        }
+        for (; c < C; ++c) {
+            const float v = x[base + (int64_t)c * n];
+            s = fma((double)v, (double)v, s);
+            const uint16_t h = bf16_rne(v);
+            hi[base + (int64_t)c * n] = h;
+            lo[base + (int64_t)c * n] = bf16_rne(v - __uint_as_float((uint32_t)h << 16));
+        }
+        nh[(int64_t)b * n + j] = (float)(-0.5 * s);
+        sq64[(int64_t)b * n + j] = s;
+    }
+    if (maxbits) {
+        float m = __double2float_ru(s);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_int(m));
+    }
+}
+
+constexpr int kSQ = 128;             // queries per block of the split filter
+constexpr int kSQStride = 256 + 64;  // bytes per LDS row of 128 bf16 query cells
+
+template <int KS32>
+constexpr int split_filter_lds_bytes() {
+    constexpr int ring = 2 * 2 * 32 * KS32 * kRStride + 2 * kBR * (int)sizeof(float);   // 2 slots x (hi, lo)
+    constexpr int qimage = 32 * KS32 * kSQStride;
+    return ring > qimage ? ring : qimage;
+}
+
+template <int KS32>
+__global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
+    const uint16_t *__restrict__ qhi, const uint16_t *__restrict__ qlo, const uint16_t *__restrict__ rhi,
+    const uint16_t *__restrict__ rlo, const float *__restrict__ rnh, int64_t nq, int64_t nr, int n_qtiles,
+    int nsplit, int64_t refs_per_split, float *__restrict__ part_val, int *__restrict__ part_idx) {
+    constexpr int C = 32 * KS32;
+    constexpr int kImg = C * kRStride;                  // one image (hi or lo) of a chunk
+    constexpr int kSlot = 2 * kImg;
+    constexpr int kInstr = C / 8;                       // LDS-direct instructions per image
+    constexpr int kPerWave = kInstr / 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *ring = lds;
+    float *nhbuf = reinterpret_cast<float *>(lds + 2 * kSlot);
+
+    int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int qt0 = bid % n_qtiles;
+    bid /= n_qtiles;
+    const int split = bid % nsplit;
+    const int b = bid / nsplit;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wq = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tr_col = 4 * (lane & 3);
+    const int tr_row = 8 * g + ((lane & 15) >> 2);
+
+    const int64_t qoff = (int64_t)b * C * nq, roff = (int64_t)b * C * nr;
+    const float *nhb = rnh + (int64_t)b * nr;
+    const int64_t q0 = (int64_t)qt0 * kSQ;
+    const int64_t rbeg = (int64_t)split * refs_per_split;
+    const int64_t rend = min(rbeg + refs_per_split, nr);
+    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
+
+    // ---- query fragments: stage the hi image, read, then the lo image, read ----------------------
+    bf16x8 bq[2][2][KS32];                              // [hi/lo][query tile][k-step]
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const uint16_t *src = (part ? qlo : qhi) + qoff;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2 * KS32; ++e) {            // C rows x 16 segments of 8 queries
+            const int seg = tid + 256 * e;
+            const int row = seg >> 4, col = (seg & 15) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(src + (int64_t)row * nq + q0 + col);
+            *reinterpret_cast<uint4 *>(lds + row * kSQStride + col * 2) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks)
+                bq[part][qt][ks] =
+                    tr_frag(lds + (ks * 32 + tr_row) * kSQStride + (wq * 32 + qt * 16 + tr_col) * 2, kSQStride);
+    }
+    __syncthreads();
+
+    // ---- reference chunks: LDS-direct loads, 8 rows x 128 B per instruction -----------------------
+    const int wq_u = __builtin_amdgcn_readfirstlane(wq);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+    auto stage = [&](int64_t r0, int slot) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const uint16_t *img = (part ? rlo : rhi) + roff;
+#pragma unroll
+            for (int e = 0; e < kPerWave; ++e) {
+                const int id = wq_u * kPerWave + e;                        // rows [8 id, 8 id + 8)
+                const int perm = ((lane >> 4) & 1) | ((id & 1) << 1);
+                const int seg = ((((lane & 7) >> 1) ^ perm) << 1) | (lane & 1);
+                const int64_t col = r0 + seg * 8;
+                const uint16_t *src = img + (int64_t)(8 * id + (lane >> 3)) * nr + (col < rend ? col : 0);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kSlot + part * kImg + id * 1024);
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(src), "s"(dst)
+                    : "memory");
+            }
+        }
+    };
+    float pre_nh = 0.f;
+    bool pre_ok = false;
+    auto fetch_nh = [&](int64_t r0) {
+        pre_ok = r0 + (tid & (kBR - 1)) < rend;
+        pre_nh = nhb[pre_ok ? r0 + (tid & (kBR - 1)) : 0];
+    };
+    auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
+    if (nchunks > 0) {
+        stage(clamp_chunk(0), 0);
+        stage(clamp_chunk(1), 1);
+        fetch_nh(clamp_chunk(0));
+        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        fetch_nh(clamp_chunk(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    TagTop1 best[2];
+    best[0].init();
+    best[1].init();
+
+    const int rd_perm = ((lane >> 3) & 1) | ((g & 1) << 1);
+    auto frag = [&](const char *img, int ri, int rt, int ks) {
+        const int slot32 = (ri * 2 + rt) ^ rd_perm;
+        return tr_frag(img + (ks * 32 + tr_row) * kRStride + slot32 * 32 + tr_col * 2, kRStride);
+    };
+    auto load_init = [&](const float *nh, int ri, int rt) {
+        const float4 t = *reinterpret_cast<const float4 *>(nh + ri * 32 + rt * 16 + 4 * g);
+        f32x4 v = {t.x, t.y, t.z, t.w};
+        return v;
+    };
+
+    f32x4 acc_a[2][2], acc_b[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            acc_b[rt][qt] = f32x4{kNegInf, kNegInf, kNegInf, kNegInf};
+            asm volatile("" : "+v"(acc_b[rt][qt]));     // opaque: keeps the loop from being peeled
+        }
+
+    // MFMAs of half-step `ri` of the slot at `img` into `now` (3 per tile and k-step); the top-list
+    // update of `prev` (half-step prev_half) is spread over them, one score per three MFMAs.
+    auto half_step = [&](const char *img, int ri, const f32x4 (&init)[2], f32x4 (&now)[2][2],
+                         const f32x4 (&prev)[2][2], int prev_half) {
+        best[0].begin_half(prev_half);
+        best[1].begin_half(prev_half);
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            ah[rt] = frag(img, ri, rt, 0);
+            al[rt] = frag(img + kImg, ri, rt, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            bf16x8 nh_[2], nl_[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                nh_[rt] = ks + 1 < KS32 ? frag(img, ri, rt, ks + 1) : ah[rt];
+                nl_[rt] = ks + 1 < KS32 ? frag(img + kImg, ri, rt, ks + 1) : al[rt];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    f32x4 t = ks ? now[rt][qt] : init[rt];
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bq[0][qt][ks], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], bq[0][qt][ks], t, 0, 0, 0);
+                    now[rt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bq[1][qt][ks], t, 0, 0, 0);
+                    // 16 scores of the previous half-step over 4 * KS32 tile visits
+                    constexpr int per = 4 / KS32 > 0 ? 4 / KS32 : 1;
+                    const int m = (ks * 4 + rt * 2 + qt) * per;
+#pragma unroll
+                    for (int e = 0; e < per; ++e) {
+                        const int sc = m + e;
+                        if (sc < 16) best[(sc >> 2) & 1].push(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                ah[rt] = nh_[rt];
+                al[rt] = nl_[rt];
+            }
+        }
+        if (KS32 == 3) {
+#pragma unroll
+            for (int sc = 12; sc < 16; ++sc)
+                best[(sc >> 2) & 1].push(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3));
+        }
+        best[0].end_half();
+        best[1].end_half();
+    };
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int slot = chunk & 1;
+        const char *img = ring + slot * kSlot;
+        const float *nh = nhbuf + slot * kBR;
+        const f32x4 init_a[2] = {load_init(nh, 0, 0), load_init(nh, 0, 1)};
+        const f32x4 init_b[2] = {load_init(nh, 1, 0), load_init(nh, 1, 1)};
+        half_step(img, 0, init_a, acc_a, acc_b, chunk * 2 - 1);
+        half_step(img, 1, init_b, acc_b, acc_a, chunk * 2);
+        // chunk end: the next chunk's images (requested a chunk ago) must have landed, and this slot
+        // must be free of readers before it is refilled
+        nhbuf[(slot ^ 1) * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage(clamp_chunk(chunk + 2), slot);
+        fetch_nh(clamp_chunk(chunk + 2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
+    if (nchunks > 0) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            best[qt].begin_half(nchunks * 2 - 1);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) best[qt].push(acc_b[rt][qt][reg], rt * 4 + reg);
+            best[qt].end_half();
+        }
+    }
+
+    const int nparts = nsplit * kT16SubStreams;
+    const int part = split * kT16SubStreams + g;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int64_t qcol = q0 + wq * 32 + qt * 16 + l15;
+        if (qcol >= nq) continue;
+#pragma unroll
+        for (int sl = 0; sl <= 1; ++sl) {
+            const int code = best[qt].code(sl);
+            int ref = -1;
+            if (code >= 0) {
                 const int tag = code & 15;
                 ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (tag >> 2) * 16 + 4 * g + (tag & 3));
             }
@@ -1262,6 +1558,8 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
 struct Plan {
     bool bf16_mfma;          // native bf16 MFMA filter (else the float32 MFMA filter)
     bool t16;                // ... on the 16x16x32 shape (top-1 only)
+    bool split;              // float32 inputs through the split-bfloat16 filter (top-1 only)
+    size_t off_qhi, off_qlo, off_rhi, off_rlo;
     int tq;                  // queries per block of the chosen filter
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
@@ -1272,11 +1570,14 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
-    p.bf16_mfma = dtype == ISPA_BF16 && C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
-    p.tq = p.bf16_mfma ? kBQ : kTQ;
-    const int chunk_refs = p.bf16_mfma ? kBR : kTR;
+    const bool fast_shape = C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
+    p.bf16_mfma = dtype == ISPA_BF16 && fast_shape;
+    p.split = dtype == ISPA_F32_SPLIT && fast_shape && k == 1;
+    p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
+    const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
     p.t16 = p.bf16_mfma && k == 1;          // top-1: the 16x16x32 kernel
-    const int substreams = p.t16 ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
+    const int substreams =
+        (p.t16 || p.split) ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
     p.ktemplate = k == 1 ? 1 : (k <= 5 ? 5 : kMaxK);
     const int64_t chunks = (nr + chunk_refs - 1) / chunk_refs;
@@ -1304,6 +1605,13 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     p.off_list = take(sizeof(int) * B * nq);
     p.off_pval = take(sizeof(float) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.off_pidx = take(sizeof(int) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
+    p.off_qhi = p.off_qlo = p.off_rhi = p.off_rlo = 0;
+    if (p.split) {
+        p.off_qhi = take(sizeof(uint16_t) * (size_t)B * C * nq);
+        p.off_qlo = take(sizeof(uint16_t) * (size_t)B * C * nq);
+        p.off_rhi = take(sizeof(uint16_t) * (size_t)B * C * nr);
+        p.off_rlo = take(sizeof(uint16_t) * (size_t)B * C * nr);
+    }
     p.total = off;
     return p;
 }
@@ -1334,6 +1642,20 @@ int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, c
     return ISPA_OK;
 }
 
+template <int KS32>
+int launch_split(dim3 grid, hipStream_t s, const uint16_t *qhi, const uint16_t *qlo, const uint16_t *rhi,
+                 const uint16_t *rlo, const float *rnh, int64_t nq, int64_t nr, const Plan &p, float *pval,
+                 int *pidx) {
+    constexpr int lds_bytes = split_filter_lds_bytes<KS32>();
+    static unsigned long long configured = 0;
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_split_kernel<KS32>), lds_bytes,
+                                         &configured))
+        return rc;
+    hipLaunchKernelGGL((nn_filter_split_kernel<KS32>), grid, dim3(256), lds_bytes, s, qhi, qlo, rhi, rlo, rnh, nq,
+                       nr, p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
+    return ISPA_OK;
+}
+
 template <int KT>
 int launch_bf16_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh,
                    int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx) {
@@ -1360,10 +1682,20 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
     // rmax and count are adjacent blocks; zero both (sizes are multiples of 256 bytes)
     ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
-    hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, q, C, nq, qnh,
-                       q64, (int *)nullptr);
-    hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr, rnh,
-                       r64, rmax);
+    uint16_t *qhi = (uint16_t *)(ws + p.off_qhi), *qlo = (uint16_t *)(ws + p.off_qlo);
+    uint16_t *rhi = (uint16_t *)(ws + p.off_rhi), *rlo = (uint16_t *)(ws + p.off_rlo);
+    if (p.split) {
+        const float *qf = reinterpret_cast<const float *>(q), *rf = reinterpret_cast<const float *>(r);
+        hipLaunchKernelGGL(nn_split_norms_kernel, dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, qf, C, nq, qhi,
+                           qlo, qnh, q64, (int *)nullptr);
+        hipLaunchKernelGGL(nn_split_norms_kernel, dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, rf, C, nr, rhi,
+                           rlo, rnh, r64, rmax);
+    } else {
+        hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, q, C, nq, qnh,
+                           q64, (int *)nullptr);
+        hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr, rnh,
+                           r64, rmax);
+    }
     if (int rc = ispa::check_launch("nn_norms_kernel")) return rc;
 
     const int64_t nblocks = (int64_t)B * p.nsplit * p.n_qtiles;
@@ -1372,7 +1704,19 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const ispa::TimingSlot timed = ispa::timing_begin(s);
     float err_rel;
     const float u = 5.9604645e-8f;   // 2^-24
-    if (p.bf16_mfma) {
+    if (p.split) {
+        // per score: three MFMAs per 32 channels at 2 ulp each (same model as below), what the split
+        // drops (at most 3.1 * 2^-16 |q||r|), the 4 tagged mantissa bits; two scores, 1.25 safety
+        err_rel = 2.f * 1.25f * (2.f * (float)(3 * (C / 32) + 1) * 2.f * u + 3.1f * 1.5258789e-5f + 1.9073486e-6f);
+        int rc;
+        switch (C / 32) {
+            case 1: rc = launch_split<1>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 2: rc = launch_split<2>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 3: rc = launch_split<3>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            default: rc = launch_split<4>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+        }
+        if (rc) return rc;
+    } else if (p.bf16_mfma) {
         // rounding model of v_mfma_f32_32x32x16_bf16: products of two bf16 are exact in float32; each
         // instruction adds 16 of them to the accumulator with a total error of at most 2 units in
         // the last place of the largest magnitude involved.  (C/16 + 1) such steps, two scores
@@ -1442,6 +1786,14 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
 }  // namespace
 
+extern "C" size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
+    if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
+    if (dtype != ISPA_F32 && dtype != ISPA_BF16 && dtype != ISPA_F32_SPLIT) return 0;
+    const size_t a = make_plan(dtype, B, C, nq, nr, k).total;
+    const size_t b = make_plan(ISPA_F32, B, C, nq, nr, k).total;     // the plan a call may fall back to
+    return a > b ? a : b;
+}
+
 extern "C" size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k) {
     if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
     // the larger of the two dtype plans, so that one workspace serves both
@@ -1460,18 +1812,19 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
                  (long long)nr);
     ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31) && B <= 65535, "problem too large");
     ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
-    ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16, "unknown dtype %d", dtype);
+    ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16 || dtype == ISPA_F32_SPLIT, "unknown dtype %d", dtype);
     Plan p = make_plan(dtype, B, C, nq, nr, k);
     if (p.bf16_mfma && (((uintptr_t)q | (uintptr_t)r) % 16 != 0)) {
         p = make_plan(ISPA_F32, B, C, nq, nr, k);       // unaligned bf16 input: converting tile loader
         p.bf16_mfma = false;
         p.t16 = false;
+        p.split = false;
     }
     if (workspace_bytes < p.total)
         return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, p.total);
     ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == ISPA_F32)
+    if (dtype == ISPA_F32 || dtype == ISPA_F32_SPLIT)
         return run((const float *)q, (const float *)r, B, C, nq, nr, k, index_base, dist, idx, (char *)workspace,
                    p, stats, s);
     return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, k, index_base, dist, idx,

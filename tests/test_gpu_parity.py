@@ -298,10 +298,12 @@ def test_zbuffer(pea, golden_geometry):
 
 
 # ---------------------------------------------------------------- dense nearest neighbour
-def _nn_check(pea, q, r, k, bf16=False, index_base=1):
+def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
     import torch
     b = q.shape[0]
-    if bf16:
+    if split:
+        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, filter="split")
+    elif bf16:
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
         dist, ind, st = pea.correspondence.dense_nn(qd, rd, k, index_base, return_stats=True)
@@ -316,7 +318,8 @@ def _nn_check(pea, q, r, k, bf16=False, index_base=1):
         scale = (q[i].reshape(q.shape[1], -1).astype(np.float64) ** 2).sum(0)[None, :] + 1.0
         finite = np.isfinite(want_d)
         # squared distances: 1e-4 relative, plus the rounding floor of the norm expansion
-        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]) + 2e-6 * np.broadcast_to(scale, want_d.shape)[finite])
+        floor = 1e-4 if split else 2e-6        # the split filter drops terms up to 3 * 2^-16 |q||r|
+        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]) + floor * np.broadcast_to(scale, want_d.shape)[finite])
         assert np.all(np.isinf(dist[i][~finite]))
     return st
 
@@ -472,6 +475,40 @@ def test_nn_bf16_shapes_and_error_model(pea):
                 worst = float(((err - tag - slack) / bound).max())
                 print(f"bf16 filter error / model bound (k={k}, mix={scale_mix}):", worst)
                 assert worst <= 0.5, worst
+
+
+def test_nn_split_filter(pea):
+    """float32 inputs through the split-bfloat16 filter: same exact indices as the float32 path."""
+    rs = np.random.RandomState(41)
+    for (b, c, nq, nr) in ((2, 128, 1024, 2048), (1, 64, 264, 520), (3, 32, 8, 136), (1, 96, 520, 1032)):
+        _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), 1, split=True)
+    # requests the split kernel does not take run as plain float32 (k > 1, odd sizes, C = 256)
+    _nn_check(pea, _unit(rs, (1, 128, 256)), _unit(rs, (1, 128, 512)), 5, split=True)
+    _nn_check(pea, _unit(rs, (2, 48, 100)), _unit(rs, (2, 48, 333)), 1, split=True)
+    _nn_check(pea, _unit(rs, (1, 256, 512)), _unit(rs, (1, 256, 1024)), 1, split=True)
+    # unnormalised features with a wide dynamic range, duplicates and near-duplicates
+    q = (rs.randn(2, 128, 512) * rs.uniform(0.01, 30.0, (1, 128, 1))).astype(np.float32)
+    r = (rs.randn(2, 128, 1024) * rs.uniform(0.01, 30.0, (1, 128, 1))).astype(np.float32)
+    r[:, :, 700] = r[:, :, 33]
+    q[:, :, 9] = r[:, :, 33]
+    for t in range(41, 60):
+        r[0, :, t] = r[0, :, 40]
+        r[0, t % 128, t] = np.nextafter(r[0, t % 128, t], np.float32(100.0))
+    q[0, :, 0] = r[0, :, 40]
+    st = _nn_check(pea, q, r, 1, split=True)
+    assert st["exact_path_queries"] >= 3
+    # full pair, self-match property at batch size
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rr = torch.randn(16, 128, 4096, device="cuda", generator=g)
+    rr = rr / rr.norm(dim=1, keepdim=True)
+    perm = torch.stack([torch.randperm(4096, device="cuda", generator=g) for _ in range(16)])
+    qq = torch.gather(rr, 2, perm[:, None, :].expand(-1, 128, -1)).contiguous()
+    d, i = pea.correspondence.dense_nn(qq, rr, 1, index_base=0, filter="split")
+    assert torch.equal(i[:, 0, :].long(), perm) and float(d.abs().max()) <= 2e-4
+    d0, i0 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0)
+    d1, i1 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0, filter="split")
+    assert torch.equal(i0, i1)
 
 
 def test_nn_top5_c256(pea):
