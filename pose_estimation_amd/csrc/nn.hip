@@ -1208,6 +1208,8 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                                                           float *__restrict__ dist,
                                                           int *__restrict__ idx, int *__restrict__ amb_count,
                                                           int *__restrict__ amb_list,
+                                                          int *__restrict__ pair_count,
+                                                          int *__restrict__ pair_list,
                                                           int *__restrict__ light_count) {
     const int b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1405,8 +1407,12 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             return;
         }
     }
+    // two queues: a global one (balanced one-query-per-block pass) and one per pair (the batched
+    // pass lets the queries of one pair share one sweep over the pair's reference map)
     const int slot = atomicAdd(amb_count, 1);
     amb_list[slot] = (int)((int64_t)b * nq + i);   // b*nq+i < 2^31 is checked on the host
+    const int pslot = atomicAdd(&pair_count[b], 1);
+    pair_list[(int64_t)b * nq + pslot] = (int)i;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1426,7 +1432,8 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                                                        const double *__restrict__ rr64, int C, int64_t nq,
                                                        int64_t nr, int k_out, int index_base, int vec_ok,
                                                        const int *__restrict__ amb_count,
-                                                       const int *__restrict__ amb_list,
+                                                       const int *__restrict__ amb_list, int skip_from,
+                                                       int n_pair, const int *__restrict__ pair_count,
                                                        float *__restrict__ dist, int *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *qs = reinterpret_cast<double *>(smem);                 // C doubles
@@ -1434,10 +1441,14 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
     int *sj = reinterpret_cast<int *>(sd + 256);                   // 256 ints
     int *sown = sj + 256;                                          // 256 ints
     const int count = *amb_count;
+    // pairs with long queues belong to nn_exact_top1_kernel, but only when queues are long on
+    // average: sharing reference reads pays off in bandwidth, not in latency
+    const bool some_batched = count >= (int64_t)skip_from * n_pair;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int64_t flat = amb_list[w];
         const int b = (int)(flat / nq);
         const int64_t i = flat % nq;
+        if (some_batched && pair_count[b] >= skip_from) continue;   // block-uniform
         const T *qcol = q + (int64_t)b * C * nq + i;
         const T *rb = r + (int64_t)b * C * nr;
         const double *rrb = rr64 + (int64_t)b * nr;
@@ -1552,6 +1563,124 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
     }
 }
 
+// Top-1 variant that shares the sweep over a pair's reference map among up to kQB queued queries
+// of that pair (the pass is bound by re-reading the map, not by arithmetic).  Same float64 chain per
+// (query, reference) as above: channels in increasing order, d2 = (qq + rr) - 2 dot, ties to the
+// lowest index.  Needs nr % 4 == 0 and 16-byte aligned rows (the generic kernel covers the rest).
+constexpr int kQB = 8;
+constexpr int kBatchMin = 4;   // shorter queues are cheaper one query per block (nn_exact_kernel)
+
+template <typename T>
+__global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict__ q, const T *__restrict__ r,
+                                                            const double *__restrict__ qq64,
+                                                            const double *__restrict__ rr64, int C, int64_t nq,
+                                                            int64_t nr, int index_base,
+                                                            const int *__restrict__ total_count,
+                                                            const int *__restrict__ pair_count,
+                                                            const int *__restrict__ pair_list,
+                                                            float *__restrict__ dist, int *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *qs = reinterpret_cast<double *>(smem);                 // [kQB][C]
+    double *sd = qs + kQB * C;                                     // 256
+    int *sj = reinterpret_cast<int *>(sd + 256);                   // 256
+    const int b = blockIdx.y;
+    const int count = pair_count[b];
+    if (count < kBatchMin || *total_count < kBatchMin * (int)gridDim.y) return;
+    const T *rb = r + (int64_t)b * C * nr;
+    const double *rrb = rr64 + (int64_t)b * nr;
+    for (int base = blockIdx.x * kQB; base < count; base += gridDim.x * kQB) {
+        const int nqry = min(kQB, count - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < kQB * C; t += 256) {
+            const int qi = t / C, c = t % C;
+            const int64_t i = pair_list[(int64_t)b * nq + base + (qi < nqry ? qi : 0)];
+            qs[t] = (double)load_as_float(q + ((int64_t)b * C + c) * nq + i);
+        }
+        __syncthreads();
+        double bd[kQB];
+        int bj[kQB];
+#pragma unroll
+        for (int qi = 0; qi < kQB; ++qi) {
+            bd[qi] = __builtin_inf();
+            bj[qi] = 0x7fffffff;
+        }
+        for (int64_t j0 = (int64_t)threadIdx.x * 4; j0 < nr; j0 += 1024) {
+            double dot[kQB][4];
+#pragma unroll
+            for (int qi = 0; qi < kQB; ++qi)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[qi][u] = 0.0;
+            const T *rp = rb + j0;
+            for (int c = 0; c < C; ++c) {
+                float rv[4];
+                if (sizeof(T) == 4) {
+                    const float4 raw = *reinterpret_cast<const float4 *>(rp + (int64_t)c * nr);
+                    rv[0] = raw.x;
+                    rv[1] = raw.y;
+                    rv[2] = raw.z;
+                    rv[3] = raw.w;
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(rp + (int64_t)c * nr);
+                    rv[0] = __uint_as_float(raw.x << 16);
+                    rv[1] = __uint_as_float(raw.x & 0xffff0000u);
+                    rv[2] = __uint_as_float(raw.y << 16);
+                    rv[3] = __uint_as_float(raw.y & 0xffff0000u);
+                }
+#pragma unroll
+                for (int qi = 0; qi < kQB; ++qi) {
+                    const double qv = qs[qi * C + c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dot[qi][u] = fma(qv, (double)rv[u], dot[qi][u]);
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < kQB; ++qi) {
+                const int64_t i = pair_list[(int64_t)b * nq + base + (qi < nqry ? qi : 0)];
+                const double qq = qq64[(int64_t)b * nq + i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double d = (qq + rrb[j0 + u]) - 2.0 * dot[qi][u];
+                    if (key_less(d, (int)(j0 + u), bd[qi], bj[qi])) {
+                        bd[qi] = d;
+                        bj[qi] = (int)(j0 + u);
+                    }
+                }
+            }
+        }
+        // block-wide lexicographic minimum per query
+        for (int qi = 0; qi < nqry; ++qi) {
+            __syncthreads();
+            double md = bd[0];
+            int mj = bj[0];
+#pragma unroll
+            for (int t = 1; t < kQB; ++t)
+                if (t == qi) {
+                    md = bd[t];
+                    mj = bj[t];
+                }
+            sd[threadIdx.x] = md;
+            sj[threadIdx.x] = mj;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (threadIdx.x < off) {
+                    const int o = threadIdx.x + off;
+                    if (key_less(sd[o], sj[o], sd[threadIdx.x], sj[threadIdx.x])) {
+                        sd[threadIdx.x] = sd[o];
+                        sj[threadIdx.x] = sj[o];
+                    }
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const int64_t i = pair_list[(int64_t)b * nq + base + qi];
+                const int64_t o = (int64_t)b * nq + i;                 // k_out == 1
+                idx[o] = sj[0] + index_base;
+                dist[o] = (float)sd[0];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1563,7 +1692,7 @@ struct Plan {
     int tq;                  // queries per block of the chosen filter
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
-    size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_list, off_pval, off_pidx, total;
+    size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_pcount, off_list, off_plist, off_pval, off_pidx, total;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1602,7 +1731,9 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     p.off_r64 = take(sizeof(double) * B * nr);
     p.off_rmax = take(sizeof(int) * B);
     p.off_count = take(16);
+    p.off_pcount = take(sizeof(int) * B);
     p.off_list = take(sizeof(int) * B * nq);
+    p.off_plist = take(sizeof(int) * B * nq);
     p.off_pval = take(sizeof(float) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.off_pidx = take(sizeof(int) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.off_qhi = p.off_qlo = p.off_rhi = p.off_rlo = 0;
@@ -1677,6 +1808,8 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     int *rmax = (int *)(ws + p.off_rmax);
     int *count = (int *)(ws + p.off_count);
     int *list = (int *)(ws + p.off_list);
+    int *pcount = (int *)(ws + p.off_pcount);
+    int *plist = (int *)(ws + p.off_plist);
     float *pval = (float *)(ws + p.off_pval);
     int *pidx = (int *)(ws + p.off_pidx);
 
@@ -1763,13 +1896,25 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
 #define ISPA_FINALIZE(KT)                                                                                     \
     hipLaunchKernelGGL((nn_finalize_kernel<T, KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
-                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, count + 1)
+                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1)
     if (p.ktemplate == 1) ISPA_FINALIZE(1);
     else if (p.ktemplate == 5) ISPA_FINALIZE(5);
     else ISPA_FINALIZE(kMaxK);
 #undef ISPA_FINALIZE
     if (int rc = ispa::check_launch("nn_finalize_kernel")) return rc;
 
+    // float64 pass: pairs with long queues (when queues are long on average) share one sweep over
+    // their reference map among kQB queries; everything else goes one query per block
+    const bool batched = k == 1 && nr % 4 == 0 && (uintptr_t)r % 16 == 0 &&
+                         (size_t)kQB * C * sizeof(double) <= 48 * 1024;
+    if (batched) {
+        int per_pair = (int)(2048 / B);
+        per_pair = per_pair < 4 ? 4 : (per_pair > 64 ? 64 : per_pair);
+        const size_t esmem = (size_t)kQB * C * sizeof(double) + 256 * (sizeof(double) + sizeof(int));
+        hipLaunchKernelGGL((nn_exact_top1_kernel<T>), dim3(per_pair, B), dim3(256), esmem, s, q, r, q64, r64, C, nq,
+                           nr, index_base, count, pcount, plist, dist, idx);
+        if (int rc = ispa::check_launch("nn_exact_top1_kernel")) return rc;
+    }
     const int64_t total_q = (int64_t)B * nq;
     const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096);
     const size_t esmem = (size_t)C * sizeof(double) + 256 * (sizeof(double) + 2 * sizeof(int));
@@ -1778,7 +1923,8 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const int evec = 16 / (int)sizeof(T);
     const int exact_vec_ok = nr % evec == 0 && (uintptr_t)r % 16 == 0;
     hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr, k,
-                       index_base, exact_vec_ok, count, list, dist, idx);
+                       index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount, dist,
+                       idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
     if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;
