@@ -1333,26 +1333,20 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
     }
     if (K > 1 && k_out <= K && v[k_out - 1] > kAbsent) {
         // Top-k, some margin too small.  Every reference that can be among the exact k nearest scores
-        // at least lim = v[k-1] - delta.  The merged list holds every kept entry above its last
-        // value, and a stream can hide an unkept reference above lim only if its own last kept score
-        // reaches lim.  If neither the merged list nor any stream ends above lim, the contenders are
-        // the merged entries >= lim, all known by index: re-score them in float64 and sort.
+        // at least lim = v[k-1] - delta.  A stream can hide an unkept reference above lim only if its
+        // own last kept score reaches lim.  If no stream does, the contenders are the kept entries
+        // >= lim of all streams, known by index: re-score them in float64 (the oracle's channel
+        // order) and keep the k smallest (distance, index).
         const float lim = v[k_out - 1] - delta;
-        bool hidden = v[K] > kAbsent && !(v[K] < lim);
+        bool hidden = false;
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+            if (v[s] != v[s]) hidden = true;
         for (int p = 0; p < nparts && !hidden; ++p) {
             const float last = part_val[(((int64_t)b * nparts + p) * (K + 1) + K) * nq + i];
             if (last != last || (last > kAbsent && last >= lim)) hidden = true;
         }
-        int nc = 0;
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            if (v[s] != v[s]) hidden = true;
-            if (v[s] > kAbsent && v[s] >= lim) {
-                if (c[s] < 0) hidden = true;
-                nc = s + 1;                              // the list is sorted: contenders are a prefix
-            }
-        }
-        if (!hidden && nc >= k_out) {
+        if (!hidden) {
             const T *qcol = q + (int64_t)b * C * nq + i;
             const double qq_d = qq64[(int64_t)b * nq + i];
             double cd[K];
@@ -1361,12 +1355,22 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             for (int e = 0; e < K; ++e) {
                 cd[e] = __builtin_inf();
                 cj[e] = 0x7fffffff;
-                if (e < nc) {
-                    const int j = c[e];
+            }
+            int nc = 0;
+            for (int p = 0; p < nparts && !hidden; ++p)
+                for (int s = 0; s < K; ++s) {
+                    const int64_t o = (((int64_t)b * nparts + p) * (K + 1) + s) * nq + i;
+                    const float x = part_val[o];
+                    if (!(x > kAbsent) || x < lim) break;       // a stream's list is descending
+                    const int j = part_idx[o];
+                    if (j < 0) {
+                        hidden = true;
+                        break;
+                    }
                     const T *rcol = r + (int64_t)b * C * nr + j;
                     double dot = 0.0;
                     int c0 = 0;
-                    for (; c0 + 8 <= C; c0 += 8) {
+                    for (; c0 + 8 <= C; c0 += 8) {             // 16 loads in flight, then the ordered chain
                         float qv[8], rv[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1379,32 +1383,32 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                     for (; c0 < C; ++c0)
                         dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
                                   (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
-                    cd[e] = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
-                    cj[e] = j;
+                    // insert into the ascending (distance, index) list; what falls off the end is dropped
+                    double xd = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+                    int xj = j;
+#pragma unroll
+                    for (int e = 0; e < K; ++e) {
+                        const bool lt = xd < cd[e] || (xd == cd[e] && xj < cj[e]);
+                        const double td = lt ? cd[e] : xd;
+                        const int tj = lt ? cj[e] : xj;
+                        cd[e] = lt ? xd : cd[e];
+                        cj[e] = lt ? xj : cj[e];
+                        xd = td;
+                        xj = tj;
+                    }
+                    ++nc;
                 }
+            if (!hidden && nc >= k_out) {
+#pragma unroll
+                for (int s = 0; s < K; ++s)
+                    if (s < k_out) {
+                        const int64_t o = ((int64_t)b * k_out + s) * nq + i;
+                        idx[o] = cj[s] + index_base;
+                        dist[o] = (float)cd[s];
+                    }
+                if (light_count) atomicAdd(light_count, 1);
+                return;
             }
-            // order the contenders by (distance, index): K is small, a full exchange sort is cheap
-#pragma unroll
-            for (int a = 0; a < K; ++a)
-#pragma unroll
-                for (int e = a + 1; e < K; ++e) {
-                    const bool sw = cd[e] < cd[a] || (cd[e] == cd[a] && cj[e] < cj[a]);
-                    const double td = sw ? cd[a] : cd[e];
-                    const int tj = sw ? cj[a] : cj[e];
-                    cd[a] = sw ? cd[e] : cd[a];
-                    cj[a] = sw ? cj[e] : cj[a];
-                    cd[e] = td;
-                    cj[e] = tj;
-                }
-#pragma unroll
-            for (int s = 0; s < K; ++s)
-                if (s < k_out) {
-                    const int64_t o = ((int64_t)b * k_out + s) * nq + i;
-                    idx[o] = cj[s] + index_base;
-                    dist[o] = (float)cd[s];
-                }
-            if (light_count) atomicAdd(light_count, 1);
-            return;
         }
     }
     // two queues: a global one (balanced one-query-per-block pass) and one per pair (the batched
