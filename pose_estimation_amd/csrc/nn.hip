@@ -162,6 +162,20 @@ struct TagTop1 {
         // v_max in front of fmaxf because t comes out of integer arithmetic)
         asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(t));
     }
+    // Two scores at once in five instructions: with m = med3(a, t1, t2) the new best is
+    // max3(a, t1, t2) and the new runner-up max(b, m) (b <= a, so whichever of a, t1, t2 is the
+    // middle one is the second largest of the three, and only b can still beat it).  Split in two
+    // halves so that a caller can place them between different MFMAs.
+    float t1, t2, mid;
+    __device__ __forceinline__ void push2_begin(float x1, int reg1, float x2, int reg2) {
+        t1 = __uint_as_float((__float_as_uint(x1) & 0xfffffff0u) | (unsigned)reg1);
+        t2 = __uint_as_float((__float_as_uint(x2) & 0xfffffff0u) | (unsigned)reg2);
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(mid) : "v"(a), "v"(t1), "v"(t2));
+    }
+    __device__ __forceinline__ void push2_end() {
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(t1), "v"(t2));
+        asm("v_max_f32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(mid));
+    }
     __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
     __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
     __device__ __forceinline__ int code(int s) const {
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     const int nk = (C + kKC - 1) / kKC;
     const int total = nchunks * nk;
 
-    TopList<K> best[2];
+    typename ListFor<K, true>::type best[2];
     best[0].init();
     best[1].init();
 
@@ -364,9 +378,16 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
             for (int ri = 0; ri < 2; ++ri) {
                 best[qi].begin_half(chunk * 2 + ri);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (ISPA_ABLATE == 4 || ISPA_ABLATE == 6) asm volatile("" ::"v"(acc[ri][qi][reg]));
-                    else best[qi].push(acc[ri][qi][reg], reg);
+                for (int reg = 0; reg < 16; reg += 2) {
+                    if (ISPA_ABLATE == 4 || ISPA_ABLATE == 6) {
+                        asm volatile("" ::"v"(acc[ri][qi][reg]), "v"(acc[ri][qi][reg + 1]));
+                    } else if constexpr (K == 1) {
+                        best[qi].push2_begin(acc[ri][qi][reg], reg, acc[ri][qi][reg + 1], reg + 1);
+                        best[qi].push2_end();
+                    } else {
+                        best[qi].push(acc[ri][qi][reg], reg);
+                        best[qi].push(acc[ri][qi][reg + 1], reg + 1);
+                    }
                 }
                 best[qi].end_half();
             }
@@ -801,8 +822,14 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
         for (int ks = 0; ks < KS32; ++ks) {
             bf16x8 an[2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                an[rt] = ks + 1 < KS32 ? frag(rimg, ri, rt, ks + 1) : frag(next_img, next_ri, rt, 0);
+            for (int rt = 0; rt < 2; ++rt) {
+                if (ISPA_ABLATE == 3 || ISPA_ABLATE == 13 || ISPA_ABLATE == 123) {                  // no LDS operand reads
+                    an[rt] = a[rt];
+                    asm volatile("" : "+v"(an[rt]));
+                } else {
+                    an[rt] = ks + 1 < KS32 ? frag(rimg, ri, rt, ks + 1) : frag(next_img, next_ri, rt, 0);
+                }
+            }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -812,13 +839,20 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
                     // 32 scores per half-step spread over its 8 * KS32 MFMAs
                     constexpr int per = 4 / KS32 > 0 ? 4 / KS32 : 1;
                     const int m = (ks * 8 + rt * 4 + qt) * per;     // scores [m, m+per) of the previous half-step
+                    // scores 2j and 2j+1 belong to the same query tile and are pushed as a pair
 #pragma unroll
                     for (int e = 0; e < per; ++e) {
                         const int sc = m + e;
                         if (sc < 32) {
                             const int prt = sc >> 4, pqt = (sc >> 2) & 3, reg = sc & 3;
-                            if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[prt][pqt][reg]));
-                            else best[pqt].push(prev[prt][pqt][reg], prt * 4 + reg);
+                            if (ISPA_ABLATE == 1 || ISPA_ABLATE == 13 || ISPA_ABLATE == 123) {
+                                asm volatile("" ::"v"(prev[prt][pqt][reg]));
+                            } else if (!(sc & 1)) {
+                                best[pqt].push2_begin(prev[prt][pqt][reg], prt * 4 + reg, prev[prt][pqt][reg + 1],
+                                                      prt * 4 + reg + 1);
+                            } else {
+                                best[pqt].push2_end();
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one MFMA, then its share of the vector work
@@ -828,8 +862,11 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
         }
         if (KS32 == 3) {                                 // 24 MFMAs covered 24 scores: the rest here
 #pragma unroll
-            for (int sc = 24; sc < 32; ++sc)
-                best[(sc >> 2) & 3].push(prev[sc >> 4][(sc >> 2) & 3][sc & 3], (sc >> 4) * 4 + (sc & 3));
+            for (int sc = 24; sc < 32; sc += 2) {
+                best[(sc >> 2) & 3].push2_begin(prev[sc >> 4][(sc >> 2) & 3][sc & 3], (sc >> 4) * 4 + (sc & 3),
+                                                prev[sc >> 4][(sc >> 2) & 3][(sc & 3) + 1], (sc >> 4) * 4 + (sc & 3) + 1);
+                best[(sc >> 2) & 3].push2_end();
+            }
         }
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) best[qt].end_half();
@@ -855,7 +892,7 @@ __global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
         nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ISPA_ABLATE != 2) stage(clamp_chunk(chunk + 2), after_slot);
+        if (ISPA_ABLATE != 2 && ISPA_ABLATE != 123) stage(clamp_chunk(chunk + 2), after_slot);
         fetch_nh(clamp_chunk(chunk + 2));
         init_a[0] = load_init(nhbuf + next_slot * kBR, 0, 0);
         init_a[1] = load_init(nhbuf + next_slot * kBR, 0, 1);
@@ -1123,7 +1160,12 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
 #pragma unroll
                     for (int e = 0; e < per; ++e) {
                         const int sc = m + e;
-                        if (sc < 16) best[(sc >> 2) & 1].push(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3));
+                        if (sc < 16) {                   // scores 2j, 2j+1 as a pair (same query tile)
+                            auto &bl = best[(sc >> 2) & 1];
+                            const f32x4 &pv = prev[sc >> 3][(sc >> 2) & 1];
+                            if (!(sc & 1)) bl.push2_begin(pv[sc & 3], (sc >> 3) * 4 + (sc & 3), pv[(sc & 3) + 1], (sc >> 3) * 4 + (sc & 3) + 1);
+                            else bl.push2_end();
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1135,8 +1177,11 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
         }
         if (KS32 == 3) {
 #pragma unroll
-            for (int sc = 12; sc < 16; ++sc)
-                best[(sc >> 2) & 1].push(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3));
+            for (int sc = 12; sc < 16; sc += 2) {
+                best[(sc >> 2) & 1].push2_begin(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3),
+                                                prev[sc >> 3][(sc >> 2) & 1][(sc & 3) + 1], (sc >> 3) * 4 + (sc & 3) + 1);
+                best[(sc >> 2) & 1].push2_end();
+            }
         }
         best[0].end_half();
         best[1].end_half();
@@ -1877,6 +1922,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         // v_mfma_f32_32x32x2_f32 is a k-ordered float32 fma chain: C+1 roundings of at most
         // u * (|q||r| + |r|^2/2) each; two scores compared, 1.25 safety.
         err_rel = 2.f * 1.25f * (float)(C + 2) * u;
+        if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
         const int elem = (int)sizeof(T);
         const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
                            ((uintptr_t)r % (4 * elem) == 0);
