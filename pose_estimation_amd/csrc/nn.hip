@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     // fetch(chunk, ks, buf): start moving stage (chunk, ks) towards LDS buffer `buf`
     auto fetch = [&](int chunk, int ks, int buf) {
         if (DIRECT) {
-            direct_tile(qb, nq, ks * kKC, q0, Qs[buf]);
+            if (ISPA_ABLATE != 7 || chunk == 0) direct_tile(qb, nq, ks * kKC, q0, Qs[buf]);
             direct_tile(rb, nr, ks * kKC, rbeg + (int64_t)chunk * kTR, Rs[buf]);
         } else {
             load_tile(qb, C, nq, ks * kKC, q0, qreg, vec_ok);
@@ -459,14 +459,16 @@ constexpr int bf16_filter_lds_bytes() {
 }
 
 template <int KS, int K>
-__global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_kernel(
+__global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx) {
     constexpr int C = 16 * KS;
     constexpr int kRBuf = C * kRStride;                 // one reference chunk image
     constexpr int kSeg = KS / 2;                        // 16-byte segments per thread per chunk
-    static_assert(KS % 2 == 0 && KS <= 8, "C must be a multiple of 32, at most 128");
+    // up to 128 channels two blocks share a CU; above that the query fragments alone take 128
+    // registers and the LDS images 144 KiB, so one block owns the CU
+    static_assert(KS % 2 == 0 && KS <= 16, "C must be a multiple of 32, at most 256");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *rbuf = lds;                                   // ring of 3 chunk images
     float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);   // ring of 3 x kBR floats
@@ -696,7 +698,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kT16SubStreams = 4;    // partial result streams per (tile, split): lane >> 4
 
 template <int KS32>
-__global__ __launch_bounds__(kBThreads, 2) void nn_filter_bf16_t16_kernel(
+__global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx) {
@@ -1748,9 +1750,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
-    const bool fast_shape = C % 32 == 0 && C <= 128 && nq % 8 == 0 && nr % 8 == 0;
-    p.bf16_mfma = dtype == ISPA_BF16 && fast_shape;
-    p.split = dtype == ISPA_F32_SPLIT && fast_shape && k == 1;
+    const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0;
+    p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && C <= 256;
+    p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 128 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
     const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
     p.t16 = p.bf16_mfma && k == 1;          // top-1: the 16x16x32 kernel
@@ -1843,7 +1845,11 @@ int launch_bf16_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const ui
         case 2: return launch_bf16<2, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
         case 4: return launch_bf16<4, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
         case 6: return launch_bf16<6, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        default: return launch_bf16<8, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 8: return launch_bf16<8, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 10: return launch_bf16<10, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 12: return launch_bf16<12, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 14: return launch_bf16<14, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        default: return launch_bf16<16, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
     }
 }
 
@@ -1912,10 +1918,13 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
                 case 1: rc = launch_t16<1>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
                 case 2: rc = launch_t16<2>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
                 case 3: rc = launch_t16<3>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                default: rc = launch_t16<4>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 4: rc = launch_t16<4>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 5: rc = launch_t16<5>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 6: rc = launch_t16<6>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 7: rc = launch_t16<7>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                default: rc = launch_t16<8>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
             }
-        } else if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
-        else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        } else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         if (rc) return rc;
     } else {

@@ -445,6 +445,11 @@ def test_nn_bf16_shapes_and_error_model(pea):
     for (b, c, nq, nr) in ((2, 64, 264, 520), (1, 32, 8, 136), (3, 96, 512, 384), (1, 128, 2048, 4096)):
         _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), 1, bf16=True)
     _nn_check(pea, _unit(rs, (2, 128, 520)), _unit(rs, (2, 128, 1032)), 5, bf16=True)
+    # 160 .. 256 channels: the same kernels with one block per CU
+    for c in (160, 192, 224, 256):
+        _nn_check(pea, _unit(rs, (2, c, 264)), _unit(rs, (2, c, 1032)), 1, bf16=True)
+        _nn_check(pea, _unit(rs, (1, c, 520)), _unit(rs, (1, c, 776)), 5, bf16=True)
+    _nn_check(pea, _unit(rs, (1, 256, 1024)), _unit(rs, (1, 256, 4096)), 8, bf16=True)
     # shapes the native path does not take (converting loader + float32 MFMA)
     _nn_check(pea, _unit(rs, (2, 48, 100)), _unit(rs, (2, 48, 333)), 1, bf16=True)
     # the margin test relies on a rounding model of the bf16 MFMA: measure the real error of the
