@@ -115,6 +115,9 @@ struct TopList {            // K+1 best scores, descending, each with its code
             c[0] = better ? code : c[0];
             v[0] = better ? x : v[0];
         } else {
+            // Most scores beat nobody's list: skip the update when no lane of the wave has a
+            // candidate (the chance falls like 64 (K+1) / t with the position t in the stream).
+            if (__builtin_amdgcn_ballot_w64(x > v[K]) == 0) return;
             // replace the last entry if better, then bubble it up (branch-free)
             const bool in = x > v[K];
             v[K] = in ? x : v[K];
