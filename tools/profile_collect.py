@@ -1,0 +1,56 @@
+"""Copies the summaries of tools/profile_all.sh from gpurun_out/ into profiles/.
+
+    python tools/profile_collect.py gpurun_out profiles r01
+
+Per workload tag: <round>_stats_<tag>_kernel_stats.csv (rocprofv3 --stats), <round>_stats_<tag>_bench.json (the bench
+line of that same profiled run), <round>_pmc_<tag>_<COUNTERS>.csv (mean counter value per kernel),
+<round>_pmc_traffic.json (tools/pmc_summary.py) and <round>_bench_default.json.
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+for d in sorted(glob.glob(os.path.join(src, "stats_*"))):
+    if not os.path.isdir(d):
+        continue
+    tag = os.path.basename(d)[len("stats_"):]
+    hits = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copy(hits[0], os.path.join(dst, f"{rnd}_stats_{tag}_kernel_stats.csv"))
+    js = os.path.join(src, f"stats_{tag}.json")
+    if os.path.exists(js):
+        lines = [l for l in open(js).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{rnd}_stats_{tag}_bench.json"), "w").write(lines[-1] + "\n")
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[len("pmc_"):]
+    hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not hits:
+        continue
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(hits[0])):
+        if "(anonymous namespace)::" not in r["Kernel_Name"] or "at::native" in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"][:160], r["Counter_Name"])
+        agg[key] += float(r["Counter_Value"])
+        cnt[key] += 1
+    with open(os.path.join(dst, f"{rnd}_pmc_{name}.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Mean_Value"])
+        for key in sorted(agg):
+            w.writerow([key[0], key[1], cnt[key], round(agg[key] / cnt[key], 1)])
+subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "pmc_summary.py"), src,
+                       os.path.join(dst, f"{rnd}_pmc_traffic.json")], stdout=subprocess.DEVNULL)
+bd = os.path.join(src, "bench_default.json")
+if os.path.exists(bd):
+    lines = [l for l in open(bd).read().splitlines() if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, f"{rnd}_bench_default.json"), "w").write(lines[-1] + "\n")
+print("collected into", dst)
