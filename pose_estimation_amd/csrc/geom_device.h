@@ -57,18 +57,35 @@ __device__ __forceinline__ bool crop_apply(const CropXform &c, int y_ge_x, int r
     return inside;
 }
 
+// Variant A in two halves, so that a caller can issue the gathers of several (point, pose) pairs
+// before it needs any of them: depth_gate_index returns the texel index to read (0 for a point
+// outside the gate, whose texel is discarded), depth_decide_a the flag.
+__device__ __forceinline__ int64_t depth_gate_index(double u, double v, int W, int ylim, int xlim, bool &gate) {
+    const double yt = trunc(v), xt = trunc(u);
+    gate = yt > 0.0 && yt < (double)ylim && xt > 0.0 && xt < (double)xlim;
+    const int y = gate ? (int)yt : 0, x = gate ? (int)xt : 0;
+    return (int64_t)y * W + x;
+}
+__device__ __forceinline__ bool depth_decide_a(bool gate, double z, float texel, double relax) {
+    return gate && fabs(z - (double)texel) <= relax;
+}
+
 template <int VARIANT>
 __device__ __forceinline__ bool depth_test(double u, double v, double z,
                                            const float *__restrict__ depth, int H, int W, int ylim,
                                            int xlim, double relax) {
     // int() truncation of the already rounded coordinate; NaN/inf fail every comparison.
     const double yt = trunc(v), xt = trunc(u);
-    if (!(yt > 0.0 && yt < (double)ylim && xt > 0.0 && xt < (double)xlim)) return false;
-    const int y = (int)yt, x = (int)xt;
+    const bool gate = yt > 0.0 && yt < (double)ylim && xt > 0.0 && xt < (double)xlim;
     if (VARIANT == ISPA_VIS_A) {
+        // branch-free: a lane outside the gate reads texel 0 and discards it, so that the gathers
+        // of several poses can be in flight at once
+        const int y = gate ? (int)yt : 0, x = gate ? (int)xt : 0;
         const double d = (double)depth[(int64_t)y * W + x];
-        return fabs(z - d) <= relax;
+        return gate && fabs(z - d) <= relax;
     } else {
+        if (!gate) return false;
+        const int y = (int)yt, x = (int)xt;
         const float r32 = (float)relax;
         float best = __builtin_inff();
         const int y1 = min(y + 2, H), x1 = min(x + 2, W);

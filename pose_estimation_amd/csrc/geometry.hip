@@ -141,13 +141,8 @@ __global__ __launch_bounds__(kThreads) void project_prune2_kernel(
     const double2 l0 = src[0], l1 = src[1], l2 = src[2];
     const int p0 = blockIdx.y * poses_per_block;
     const int p1 = min(p0 + poses_per_block, n_pose);
-    for (int p = p0; p < p1; ++p) {
-        double2 u, v, z;
-        project_point(cams + 12 * (int64_t)p, l0.x, l0.y, l1.x, u.x, v.x, z.x);
-        project_point(cams + 12 * (int64_t)p, l1.y, l2.x, l2.y, u.y, v.y, z.y);
-        const float *d = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
-        const bool vis0 = depth_test<VARIANT>(u.x, v.x, z.x, d, H, W, ylim, xlim, relax);
-        const bool vis1 = depth_test<VARIANT>(u.y, v.y, z.y, d, H, W, ylim, xlim, relax);
+    // crop, remap and store one pose's pair of points
+    auto finish = [&](int p, double2 u, double2 v, double2 z, bool vis0, bool vis1) {
         bool in0 = true, in1 = true;
         if (crop) {
             const int32_t *c = crop + (crop_per_pose ? 4 * (int64_t)p : 0);
@@ -164,6 +159,37 @@ __global__ __launch_bounds__(kThreads) void project_prune2_kernel(
         *reinterpret_cast<uchar2 *>(truth + t) = make_uchar2(vis0 && in0, vis1 && in1);
         if (truth_depth) *reinterpret_cast<uchar2 *>(truth_depth + t) = make_uchar2(vis0, vis1);
         if (truth_crop) *reinterpret_cast<uchar2 *>(truth_crop + t) = make_uchar2(in0, in1);
+    };
+    int p = p0;
+    if (VARIANT == ISPA_VIS_A) {
+        // two poses per iteration: the four depth gathers are issued together, after both
+        // projections, and waited for once
+        for (; p + 1 < p1; p += 2) {
+            double2 ua, va, za, ub, vb, zb;
+            project_point(cams + 12 * (int64_t)p, l0.x, l0.y, l1.x, ua.x, va.x, za.x);
+            project_point(cams + 12 * (int64_t)p, l1.y, l2.x, l2.y, ua.y, va.y, za.y);
+            project_point(cams + 12 * (int64_t)(p + 1), l0.x, l0.y, l1.x, ub.x, vb.x, zb.x);
+            project_point(cams + 12 * (int64_t)(p + 1), l1.y, l2.x, l2.y, ub.y, vb.y, zb.y);
+            const float *da = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
+            const float *db = depth + (depth_per_pose ? (int64_t)(p + 1) * H * W : 0);
+            bool ga0, ga1, gb0, gb1;
+            const int64_t ia0 = depth_gate_index(ua.x, va.x, W, ylim, xlim, ga0);
+            const int64_t ia1 = depth_gate_index(ua.y, va.y, W, ylim, xlim, ga1);
+            const int64_t ib0 = depth_gate_index(ub.x, vb.x, W, ylim, xlim, gb0);
+            const int64_t ib1 = depth_gate_index(ub.y, vb.y, W, ylim, xlim, gb1);
+            const float ta0 = da[ia0], ta1 = da[ia1], tb0 = db[ib0], tb1 = db[ib1];
+            finish(p, ua, va, za, depth_decide_a(ga0, za.x, ta0, relax), depth_decide_a(ga1, za.y, ta1, relax));
+            finish(p + 1, ub, vb, zb, depth_decide_a(gb0, zb.x, tb0, relax), depth_decide_a(gb1, zb.y, tb1, relax));
+        }
+    }
+    for (; p < p1; ++p) {
+        double2 u, v, z;
+        project_point(cams + 12 * (int64_t)p, l0.x, l0.y, l1.x, u.x, v.x, z.x);
+        project_point(cams + 12 * (int64_t)p, l1.y, l2.x, l2.y, u.y, v.y, z.y);
+        const float *d = depth + (depth_per_pose ? (int64_t)p * H * W : 0);
+        const bool vis0 = depth_test<VARIANT>(u.x, v.x, z.x, d, H, W, ylim, xlim, relax);
+        const bool vis1 = depth_test<VARIANT>(u.y, v.y, z.y, d, H, W, ylim, xlim, relax);
+        finish(p, u, v, z, vis0, vis1);
     }
 }
 
