@@ -192,6 +192,25 @@ int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int
 int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
                        int W, int grid, float *out, float *workspace, void *stream);
 
+/* proxy_renderer.proxy_render's lookup, batched
+ *   classifier_code/train_test_scripts/utils/proxy_renderer.py:100-106 (argmin) and :138-151 (normalize)
+ * view_params (n_view,3), stored (n_stored,3) f64 rows [azimuth, elevation, tilt] in degrees.
+ * index[v] = first j minimising || wrap(stored[j] - view[v]) * [1, 1/8, 1/8] ||_2, differences wrapped
+ * to [-180,180) / [-90,90) / [-180,180) as normalize does.  distance (optional, may be NULL) = that norm. */
+int ispa_nearest_view(const double *view_params, int n_view, const double *stored, int n_stored,
+                      int32_t *index, double *distance, void *stream);
+
+/* HardNegativeProcessingLayer.forward, index decode + PCK hit counts
+ *   ucn_code/lib/layers/hard_negative_processing_layer.py:44-58 (_ind2coord), :188-190, :218-234
+ * ind (B,k,n) i32 as ispa_nn_topk writes it (row 0 = nearest); correspondences (B,n,5) f64 rows
+ * [x1, y1, x2, y2, flag]; a row counts iff flag == 1.  Image coordinate of index j (after subtracting
+ * index_base): ((j mod width) * downsampling, floor(j / width) * downsampling).
+ * counts (n_radii,B) i32: rows whose coordinate is closer than radii[r] to (x2, y2). */
+#define ISPA_PCK_MAX_RADII 8
+int ispa_pck_counts(const int32_t *ind, int B, int k, int64_t n, const double *correspondences, int width,
+                    double downsampling, int index_base, const double *radii, int n_radii,
+                    int32_t *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

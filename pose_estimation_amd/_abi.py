@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ISPA_HIP_LIBRARY") or os.path.join(_HERE, "libispa_hi
 ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1
 F32, BF16, F32_SPLIT = 0, 1, 2
+PCK_MAX_RADII = 8
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -42,6 +43,8 @@ SIGNATURES = {
     "ispa_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ispa_corr_map_eccv": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ispa_corr_map_acmm": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "ispa_nearest_view": (_i, [_p, _i, _p, _i, _p, _p, _p]),
+    "ispa_pck_counts": (_i, [_p, _i, _i, _i64, _p, _i, _d, _i, _p, _i, _p, _p]),
 }
 
 

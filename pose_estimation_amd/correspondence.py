@@ -91,15 +91,25 @@ def ind2coord(ind, width, downsampling_factor=4, index_base=1):
 
 def pck(ind, correspondences, width, radii, downsampling_factor=4, index_base=1):
     """Hit counts of the 1-NN matches, as HardNegativeProcessingLayer.forward computes them
-    (hard_negative_processing_layer.py:188-190,218-234).
+    (hard_negative_processing_layer.py:188-190,218-234), on the device (ispa_pck_counts).
 
-    ind (B,k,n) from dense_nn; correspondences (B,n,5) rows [x1, y1, x2, y2, flag]; a row takes
-    part iff flag == 1; a hit is an image-space distance below the radius.  Returns (len(radii), B)."""
-    xy = ind2coord(ind, width, downsampling_factor, index_base)[:, 0]          # (B,n,2)
-    corr = np.asarray(correspondences)
-    valid = corr[:, :, 4] == 1
-    dist = np.sqrt(np.sum((xy - corr[:, :, 2:4]) ** 2, axis=2))
-    return np.stack([np.sum((dist < r) & valid, axis=1) for r in radii]).astype(np.float64)
+    ind (B,k,n) from dense_nn (array or device tensor); correspondences (B,n,5) rows
+    [x1, y1, x2, y2, flag]; a row takes part iff flag == 1; a hit is an image-space distance below
+    the radius.  Returns (len(radii), B) float64 like the layer's `pcks` array."""
+    radii = [float(r) for r in radii]
+    if len(radii) > _abi.PCK_MAX_RADII:
+        raise ValueError(f"at most {_abi.PCK_MAX_RADII} radii per call")
+    as_tensor = dv.is_tensor(ind)
+    it = dv.to_dev(ind, torch.int32)
+    ct = dv.to_dev(correspondences, torch.float64)
+    if it.dim() != 3 or ct.dim() != 3 or ct.shape[2] != 5 or ct.shape[:2] != (it.shape[0], it.shape[2]):
+        raise ValueError("ind must be (B,k,n) and correspondences (B,n,5)")
+    b, k, n = it.shape
+    rt = dv.to_dev(np.asarray(radii, dtype=np.float64), torch.float64)
+    counts = dv.empty((len(radii), b), torch.int32)
+    _abi.check(_abi.lib.ispa_pck_counts(dv.ptr(it), b, k, n, dv.ptr(ct), int(width), float(downsampling_factor),
+                                        int(index_base), dv.ptr(rt), len(radii), dv.ptr(counts), dv.stream_ptr()))
+    return dv.back(counts.to(torch.float64), as_tensor)
 
 
 def resize_bilinear(x, size):
@@ -175,13 +185,25 @@ def knn_inds_to_grid(knn_xy, grid=28, image=224):
     return (np.clip(np.asarray(knn_xy, dtype=np.float64), 0, image - 1) / (float(image) / grid)).astype(np.int64)
 
 
-def nearest_view(view_params, param_np):
+def nearest_view(view_params, param_np, return_distance=False):
     """proxy_renderer.proxy_render's lookup (lines 101-106): index of the stored pose closest to
-    view_params, angle differences wrapped, elevation and tilt weighted 1/8."""
-    d = np.array(param_np, dtype=np.float64) - np.asarray(view_params, dtype=np.float64)
-    for col, half in ((0, 180.0), (1, 90.0), (2, 180.0)):
-        c = d[:, col].copy()
-        d[c >= half, col] -= 2 * half
-        d[c < -half, col] += 2 * half
-    d[:, 1:] /= 8.0
-    return int(np.argmin(np.linalg.norm(d, axis=1)))
+    view_params, angle differences wrapped, elevation and tilt weighted 1/8 (ispa_nearest_view).
+
+    view_params (3,) -> int, or (n,3) -> (n,) int32 array; param_np (P,3) stored [az, el, tilt]
+    (array or device tensor: a table kept on the device is not copied again)."""
+    v = np.asarray(view_params, dtype=np.float64) if not dv.is_tensor(view_params) else view_params
+    single = v.ndim == 1
+    vt = dv.to_dev(v, torch.float64).reshape(-1, 3)
+    st = dv.to_dev(param_np, torch.float64)
+    if st.dim() != 2 or st.shape[1] != 3:
+        raise ValueError("param_np must be (P,3)")
+    idx = dv.empty((vt.shape[0],), torch.int32)
+    dist = dv.empty((vt.shape[0],), torch.float64) if return_distance else None
+    _abi.check(_abi.lib.ispa_nearest_view(dv.ptr(vt), vt.shape[0], dv.ptr(st), st.shape[0], dv.ptr(idx),
+                                          dv.ptr(dist), dv.stream_ptr()))
+    idx = idx.cpu().numpy()
+    out = int(idx[0]) if single else idx
+    if return_distance:
+        d = dist.cpu().numpy()
+        return out, (float(d[0]) if single else d)
+    return out

@@ -51,9 +51,10 @@ inline int allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *
     int dev = 0;
     ISPA_HIP(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(*done_mask & bit)) {
+    // host threads may race here: setting the attribute twice is harmless, the mask update is atomic
+    if (!(__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit)) {
         ISPA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        *done_mask |= bit;
+        __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
     }
     return ISPA_OK;
 }

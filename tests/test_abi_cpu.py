@@ -33,6 +33,11 @@ def test_argument_checks_do_not_need_a_gpu():
     assert rc == -1 and b"gate" in _abi.lib.ispa_last_error()
     rc = _abi.lib.ispa_project(None, 0, None, 0, None, None)
     assert rc == 0                                           # empty input is a no-op
+    rc = _abi.lib.ispa_nearest_view(1, 1, 1, 0, 1, None, None)
+    assert rc == -1 and b"no stored poses" in _abi.lib.ispa_last_error()
+    rc = _abi.lib.ispa_pck_counts(1, 1, 1, 4, 1, 56, 4.0, 1, 1, 9, 1, None)
+    assert rc == -1 and b"radii" in _abi.lib.ispa_last_error()
+    assert _abi.lib.ispa_pck_counts(None, 0, 1, 0, None, 56, 4.0, 1, None, 0, None, None) == 0
 
 
 def test_host_helpers_without_gpu():
@@ -59,9 +64,3 @@ def test_host_helpers_without_gpu():
     assert np.array_equal(correspondence.knn_inds_to_grid(xy), okp.knn_inds_to_grid(xy))
     ind = rs.randint(1, 3137, (2, 1, 50))
     assert np.array_equal(correspondence.ind2coord(ind, 56), okp.ind2coord(ind, 56))
-    corr = np.concatenate([rs.uniform(0, 224, (2, 50, 4)), rs.choice([1.0, 0.0, -1.0], (2, 50, 1))], axis=2)
-    corr[:, :10, 2:4] = okp.ind2coord(ind[:, 0, :10], 56) + 3.0            # planted near-hits
-    assert np.array_equal(correspondence.pck(ind, corr, 56, [10, 20, 40]), okp.pck_counts(ind, corr, 56, [10, 20, 40]))
-    stored = np.stack([rs.uniform(0, 360, 500), rs.uniform(-20, 20, 500), rs.uniform(-20, 20, 500)], 1)
-    for view in ([0, 10, 0], [359, 0, 0], [120, 10, 0], [181, -3, 4]):
-        assert correspondence.nearest_view(view, stored) == okp.nearest_view(view, stored)

@@ -576,6 +576,65 @@ def test_projection_config4_pose_sweep(pea):
     assert np.array_equal(o2[1], out[1][:, :99999]) and np.array_equal(t2[1], truth[1][:99999])
 
 
+# ---------------------------------------------------------------- consumers: nearest view, PCK
+def test_nearest_view_matches_numpy(pea):
+    import torch
+    rs = np.random.RandomState(17)
+    stored = np.stack([rs.uniform(0, 360, 8000), rs.uniform(-20, 40, 8000), rs.uniform(-30, 30, 8000)], 1)
+    stored[4000] = stored[77]                         # duplicates: the first one wins
+    stored[7999] = stored[77]
+    views = np.stack([rs.uniform(-10, 370, 600), rs.uniform(-30, 50, 600), rs.uniform(-40, 40, 600)], 1)
+    views[0] = stored[77]                             # exact hit on the duplicated pose
+    views[1] = [359.5, 0, 0]                          # wraps past 360
+    views[2] = stored[5] + [180.0, 0, 0]              # difference exactly -180: not wrapped
+    views[3] = stored[6] - [180.0, 0, 0]              # difference exactly +180: wrapped
+    views[4] = [0, 95, 185]                           # elevation and tilt wrap
+    got, dist = pea.correspondence.nearest_view(views, stored, return_distance=True)
+    for v in range(len(views)):
+        assert got[v] == okp.nearest_view(views[v], stored), v
+        d = okp.normalize_pose_delta(stored - views[v])
+        d[:, 1:] /= 8.0
+        assert dist[v] == np.linalg.norm(d, axis=1).min()        # bit-exact float64
+    assert got[0] == 77
+    # single pose in, int out; a table already on the device is used in place
+    table = torch.from_numpy(stored).cuda()
+    one = pea.correspondence.nearest_view([120, 10, 0], table)
+    assert isinstance(one, int) and one == okp.nearest_view([120, 10, 0], stored)
+    from pose_estimation_amd._abi import IspaError
+    with pytest.raises(IspaError):
+        pea.correspondence.nearest_view([0, 0, 0], np.zeros((0, 3)))
+
+
+def test_pck_counts_match_numpy(pea):
+    import torch
+    rs = np.random.RandomState(23)
+    b, k, n, width = 3, 2, 700, 56
+    ind = rs.randint(1, width * width + 1, (b, k, n)).astype(np.int32)
+    corr = np.concatenate([rs.uniform(0, 224, (b, n, 4)), rs.choice([1.0, 0.0, -1.0], (b, n, 1))], axis=2)
+    xy = okp.ind2coord(ind[:, 0, :], width)
+    corr[:, :40, 2:4] = xy[:, :40] + rs.uniform(-12, 12, (b, 40, 2))     # near-hits around the radii
+    corr[:, 40:50, 2:4] = xy[:, 40:50] + [6.0, 8.0]                         # distance exactly 10: not < 10
+    corr[:, 50:60, 2:4] = xy[:, 50:60]                                      # distance 0
+    corr[:, :60, 4] = 1.0
+    radii = [10, 20, 40]
+    want = okp.pck_counts(ind, corr, width, radii)
+    got = pea.correspondence.pck(ind, corr, width, radii)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    assert want[0].min() >= 10                                              # the planted cases are in play
+    # zero-based indices, device tensors in -> device tensor out, float32 correspondences
+    got0 = pea.correspondence.pck(torch.from_numpy(ind - 1).cuda(), torch.from_numpy(corr.astype(np.float32)).cuda(),
+                                  width, radii, index_base=0)
+    assert torch.is_tensor(got0)
+    assert np.array_equal(got0.cpu().numpy(), okp.pck_counts(ind, corr.astype(np.float32), width, radii))
+    # straight from dense_nn
+    q, r = _unit(rs, (2, 32, 56 * 56)), _unit(rs, (2, 32, 56 * 56))
+    dist, nn = pea.correspondence.dense_nn(q, r, 1)
+    c2 = np.concatenate([rs.uniform(0, 224, (2, 56 * 56, 4)), np.ones((2, 56 * 56, 1))], axis=2)
+    assert np.array_equal(pea.correspondence.pck(nn, c2, 56, [30, 60]), okp.pck_counts(nn, c2, 56, [30, 60]))
+    with pytest.raises(ValueError):
+        pea.correspondence.pck(ind, corr, width, list(range(1, 10)))
+
+
 # ---------------------------------------------------------------- correlation maps
 @pytest.mark.parametrize("tag", ["b1k1", "b2k10", "b3k14"])
 def test_corr_eccv_golden(pea, golden_correlation, tag):
