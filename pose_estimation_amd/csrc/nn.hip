@@ -419,6 +419,178 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2a'. float32 filter with the query fragments resident in registers (C = 16 * NKS <= 128, float
+// input, aligned rows).  Same tile (128 queries x 128-reference chunks, 2 x 2 waves of 64 x 64) and
+// the same MFMA chain as nn_filter_f32_kernel, but a wave loads its 64 queries once, straight into
+// MFMA operand layout (C/2 registers per 32-query tile), so only reference stages pass through LDS:
+// a ring of four 16-channel stages filled by LDS-direct loads three stages ahead.  Two blocks per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRing = 4;      // reference stages in LDS; loads run kRing - 1 stages ahead
+
+template <int NKS, int K>
+__global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
+    const float *__restrict__ q, const float *__restrict__ r, const float *__restrict__ rnh, int64_t nq, int64_t nr,
+    int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val, int *__restrict__ part_idx) {
+    constexpr int C = NKS * kKC;
+    __shared__ __attribute__((aligned(16))) float Rs[kRing][kKC][kTR];
+    __shared__ float Nh[2][kTR];
+
+    int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int qt = bid % n_qtiles;
+    bid /= n_qtiles;
+    const int split = bid % nsplit;
+    const int b = bid / nsplit;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wq = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const float *qb = q + (int64_t)b * C * nq;
+    const float *rb = r + (int64_t)b * C * nr;
+    const float *nhb = rnh + (int64_t)b * nr;
+    const int64_t q0 = (int64_t)qt * kTQ;
+    const int64_t rbeg = (int64_t)split * refs_per_split;
+    const int64_t rend = min(rbeg + refs_per_split, nr);
+    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+    const int total = nchunks * NKS;
+
+    // reference stage `st` (chunk st / NKS, channels 16 (st % NKS) ..) -> ring slot; one wave
+    // instruction moves 1 KiB = 2 rows, this wave owns rows 4 wave .. 4 wave + 3.  Stages past the
+    // end re-fetch the last one (every wave issues the same number of loads, which the vmcnt
+    // arithmetic below relies on); columns past the end of the range re-read column 0.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(&Rs[0][0][0]);
+    auto fetch = [&](int st, int slot) {
+        const int s2 = st < total ? st : total - 1;
+        const int chunk = s2 / NKS, ks = s2 % NKS;
+        const int64_t n0 = rbeg + (int64_t)chunk * kTR;
+        const int64_t col = n0 + d_col < nr ? n0 + d_col : 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = 4 * wave_u + 2 * e;
+            const float *src = rb + (int64_t)(ks * kKC + row + d_row) * nr + col;
+            const unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds0 + ((slot * kKC + row) * kTR) * 4);
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(ldsaddr)
+                : "memory");
+        }
+    };
+    auto load_nh = [&](int chunk) {
+        const int64_t j = rbeg + (int64_t)chunk * kTR + (threadIdx.x & (kTR - 1));
+        return (chunk < nchunks && j < rend) ? nhb[j] : kNegInf;
+    };
+
+    // query fragments: lane (l31, h) of k-step kk holds channel 2 kk + h of query column l31
+    float bq[2][C / 2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int64_t col = q0 + wq * 64 + qi * 32 + l31;
+        const float *src = qb + (col < nq ? col : 0);
+#pragma unroll
+        for (int kk = 0; kk < C / 2; ++kk) bq[qi][kk] = src[(int64_t)(2 * kk + h) * nq];
+    }
+    if (total > 0) Nh[0][threadIdx.x & (kTR - 1)] = load_nh(0);
+    float nh_next = load_nh(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // plain loads done before the counted ones start
+    if (total > 0) {
+#pragma unroll
+        for (int e = 0; e < kRing - 1; ++e) fetch(e, e);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kRing - 2)) : "memory");   // stage 0 landed
+    }
+    __syncthreads();
+
+    typename ListFor<K, true>::type best[2];
+    best[0].init();
+    best[1].init();
+
+    int st = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float init = Nh[chunk & 1][wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+                acc[ri][0][reg] = init;
+                acc[ri][1][reg] = init;
+            }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks, ++st) {
+            const int slot = st & (kRing - 1);
+            // the slot of stage st - 1 is free: every wave passed the barrier that ended it
+            fetch(st + kRing - 1, (st + kRing - 1) & (kRing - 1));
+            float a0 = Rs[slot][h][wr * 64 + l31], a1 = Rs[slot][h][wr * 64 + 32 + l31];
+#pragma unroll
+            for (int kk = 0; kk < kKC; kk += 2) {
+                float a0n = a0, a1n = a1;
+                if (kk + 2 < kKC) {
+                    a0n = Rs[slot][kk + 2 + h][wr * 64 + l31];
+                    a1n = Rs[slot][kk + 2 + h][wr * 64 + 32 + l31];
+                }
+                const float b0 = bq[0][ks * (kKC / 2) + kk / 2], b1 = bq[1][ks * (kKC / 2) + kk / 2];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = a0n;
+                a1 = a1n;
+            }
+            if (ks == NKS - 1) {                         // norms of the next chunk, read a chunk ago
+                Nh[(chunk + 1) & 1][threadIdx.x & (kTR - 1)] = nh_next;
+                nh_next = load_nh(chunk + 2);
+            }
+            // stage st + 1 landed: at most the kRing - 2 youngest stages (and the norm load) outstanding
+            if (ks == NKS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kRing - 2) + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kRing - 2)) : "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                best[qi].begin_half(chunk * 2 + ri);
+#pragma unroll
+                for (int reg = 0; reg < 16; reg += 2) {
+                    if constexpr (K == 1) {
+                        best[qi].push2_begin(acc[ri][qi][reg], reg, acc[ri][qi][reg + 1], reg + 1);
+                        best[qi].push2_end();
+                    } else {
+                        best[qi].push(acc[ri][qi][reg], reg);
+                        best[qi].push(acc[ri][qi][reg + 1], reg + 1);
+                    }
+                }
+                best[qi].end_half();
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
+
+    const int nparts = nsplit * kSubStreams;
+    const int part = split * kSubStreams + wr * 2 + h;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
+        if (qcol >= nq) continue;
+#pragma unroll
+        for (int s = 0; s <= K; ++s) {
+            const int code = best[qi].code(s);
+            int ref = -1;
+            if (code >= 0) {
+                const int reg = code & 15, ri = (code >> 4) & 1;
+                ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+            }
+            const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
+            part_val[o] = best[qi].value(s);
+            part_idx[o] = ref;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 2b. filter pass, bfloat16 MFMA (v_mfma_f32_32x32x16_bf16, float32 accumulation)
 //
 // One 256-thread block = 256 queries x (a split of) all references; wave w owns queries
@@ -1943,7 +2115,21 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 #define ISPA_F32_FILTER(KT, D)                                                                                 \
     hipLaunchKernelGGL((nn_filter_f32_kernel<T, KT, D>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,    \
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok)
-        if (p.ktemplate == 1) {
+        // top-1 with at most 128 channels: the variant that keeps the query fragments in registers
+        const bool qreg = direct && C % 32 == 0 && C <= 128 && p.ktemplate == 1;
+        if (qreg) {
+            const float *qf = reinterpret_cast<const float *>(q), *rf = reinterpret_cast<const float *>(r);
+#define ISPA_QREG(NKS)                                                                                        \
+    hipLaunchKernelGGL((nn_filter_f32_qreg_kernel<NKS, 1>), grid, dim3(kThreads), 0, s, qf, rf, rnh, nq, nr,   \
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx)
+            switch (C / 32) {
+                case 1: ISPA_QREG(2); break;
+                case 2: ISPA_QREG(4); break;
+                case 3: ISPA_QREG(6); break;
+                default: ISPA_QREG(8); break;
+            }
+#undef ISPA_QREG
+        } else if (p.ktemplate == 1) {
             if (direct) ISPA_F32_FILTER(1, true); else ISPA_F32_FILTER(1, false);
         } else if (p.ktemplate == 5) {
             if (direct) ISPA_F32_FILTER(5, true); else ISPA_F32_FILTER(5, false);

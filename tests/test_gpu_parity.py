@@ -429,6 +429,14 @@ def test_nn_full_pair_64x64x128(pea):
     assert st["exact_path_queries"] < 4096 // 8
 
 
+def test_nn_f32_query_resident_filter_shapes(pea):
+    # float32 top-1 with C in {32,64,96,128} and 4-aligned cell counts takes the filter that keeps the
+    # query fragments in registers; ragged tiles, a split reference range and a single chunk
+    rs = np.random.RandomState(77)
+    for (b, c, nq, nr) in ((2, 128, 260, 1028), (1, 96, 132, 516), (3, 64, 4, 2052), (1, 32, 1024, 100), (1, 128, 64, 8192)):
+        _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), 1)
+
+
 def test_nn_batch_and_bf16(pea):
     rs = np.random.RandomState(8)
     q = _unit(rs, (6, 128, 1024))
