@@ -287,19 +287,21 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     // re-read column 0 (finite values; masked references / unwritten queries).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+    // the row part of the address is uniform (scalar base), the lane part a 32-bit offset
     auto direct_tile = [&](const T *x, int64_t n, int c0, int64_t n0, float (*dst)[kTQ]) {
         const int64_t col = n0 + d_col < n ? n0 + d_col : 0;
+        const unsigned voff = (unsigned)(((int64_t)d_row * n + col) * 4);
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(&dst[0][0]);
 #pragma unroll
         for (int e = 0; e < kKC / 8; ++e) {
             const int row = (kKC / 4) * wave_u + 2 * e;
-            const T *src = x + (int64_t)(c0 + row + d_row) * n + col;
+            const uint64_t sbase = (uint64_t)x + (uint64_t)(c0 + row) * (uint64_t)n * 4u;
             const unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds0 + row * kTQ * 4);
             unsigned keep;
             asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                 : "=&s"(keep)
-                : "v"(src), "s"(ldsaddr)
+                : "v"(voff), "s"(ldsaddr), "s"(sbase)
                 : "memory");
         }
     };
@@ -427,6 +429,31 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 4;      // reference stages in LDS; loads run kRing - 1 stages ahead
 
+// One 16-channel x 128-reference stage -> LDS ring slot, two LDS-direct instructions per wave (1 KiB =
+// 2 rows each; this wave owns rows 4 wave .. 4 wave + 3).  The row part of the address is uniform
+// and goes into the scalar base, the per-lane part (row parity, column) is the 32-bit offset `voff`,
+// so a stage costs no vector address arithmetic.
+__device__ __forceinline__ unsigned stage_voff(int64_t nr, int64_t n0, int lane) {
+    const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+    const int64_t col = n0 + d_col < nr ? n0 + d_col : 0;   // past the end: column 0 (masked by the norms)
+    return (unsigned)(((int64_t)d_row * nr + col) * 4);
+}
+__device__ __forceinline__ void stage_fetch(const float *rb, int64_t nr, int ks, int wave_u, unsigned voff,
+                                            unsigned lds_slot) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 4 * wave_u + 2 * e;
+        const uint64_t sbase = (uint64_t)rb + (uint64_t)(ks * kKC + row) * (uint64_t)nr * 4u;
+        const unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds_slot + row * kTR * 4);
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(ldsaddr), "s"(sbase)
+            : "memory");
+    }
+}
+
 template <int NKS, int K>
 __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     const float *__restrict__ q, const float *__restrict__ r, const float *__restrict__ rnh, int64_t nq, int64_t nr,
@@ -460,25 +487,15 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     // end re-fetch the last one (every wave issues the same number of loads, which the vmcnt
     // arithmetic below relies on); columns past the end of the range re-read column 0.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int d_row = lane >> 5, d_col = (lane & 31) * 4;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(&Rs[0][0][0]);
-    auto fetch = [&](int st, int slot) {
-        const int s2 = st < total ? st : total - 1;
-        const int chunk = s2 / NKS, ks = s2 % NKS;
-        const int64_t n0 = rbeg + (int64_t)chunk * kTR;
-        const int64_t col = n0 + d_col < nr ? n0 + d_col : 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = 4 * wave_u + 2 * e;
-            const float *src = rb + (int64_t)(ks * kKC + row + d_row) * nr + col;
-            const unsigned ldsaddr = __builtin_amdgcn_readfirstlane(lds0 + ((slot * kKC + row) * kTR) * 4);
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(src), "s"(ldsaddr)
-                : "memory");
-        }
+    // stage (chunk, ks) -> ring slot; chunks past the end re-fetch the last one into a slot nobody
+    // reads (every wave issues the same number of loads, which the vmcnt arithmetic relies on)
+    auto chunk_voff = [&](int chunk) {
+        const int c = chunk < nchunks ? chunk : nchunks - 1;
+        return stage_voff(nr, rbeg + (int64_t)c * kTR, lane);
+    };
+    auto fetch = [&](unsigned voff, int ks, int slot) {
+        stage_fetch(rb, nr, ks, wave_u, voff, lds0 + slot * (kKC * kTR * 4));
     };
     auto load_nh = [&](int chunk) {
         const int64_t j = rbeg + (int64_t)chunk * kTR + (threadIdx.x & (kTR - 1));
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // plain loads done before the counted ones start
     if (total > 0) {
 #pragma unroll
-        for (int e = 0; e < kRing - 1; ++e) fetch(e, e);
+        for (int e = 0; e < kRing - 1; ++e) fetch(chunk_voff(e / NKS), e % NKS, e);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kRing - 2)) : "memory");   // stage 0 landed
     }
     __syncthreads();
@@ -519,11 +536,14 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
                 acc[ri][0][reg] = init;
                 acc[ri][1][reg] = init;
             }
+        unsigned voff[(NKS + kRing - 2) / NKS + 1];
+#pragma unroll
+        for (int d = 0; d <= (NKS + kRing - 2) / NKS; ++d) voff[d] = chunk_voff(chunk + d);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks, ++st) {
             const int slot = st & (kRing - 1);
             // the slot of stage st - 1 is free: every wave passed the barrier that ended it
-            fetch(st + kRing - 1, (st + kRing - 1) & (kRing - 1));
+            fetch(voff[(ks + kRing - 1) / NKS], (ks + kRing - 1) % NKS, (st + kRing - 1) & (kRing - 1));
             float a0 = Rs[slot][h][wr * 64 + l31], a1 = Rs[slot][h][wr * 64 + 32 + l31];
 #pragma unroll
             for (int kk = 0; kk < kKC; kk += 2) {
@@ -2111,7 +2131,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
                            ((uintptr_t)r % (4 * elem) == 0);
         const bool direct = sizeof(T) == 4 && vec_ok && C % kKC == 0 && (uintptr_t)q % 16 == 0 &&
-                            (uintptr_t)r % 16 == 0;
+                            (uintptr_t)r % 16 == 0 && nq < (1 << 28) && nr < (1 << 28);   // 32-bit lane offsets
 #define ISPA_F32_FILTER(KT, D)                                                                                 \
     hipLaunchKernelGGL((nn_filter_f32_kernel<T, KT, D>), grid, dim3(kThreads), 0, s, q, r, rnh, C, nq, nr,    \
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, vec_ok)
