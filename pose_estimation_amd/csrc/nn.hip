@@ -627,6 +627,26 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// One LDS-direct instruction (64 lanes x 16 bytes -> 1 KiB of LDS at `lds_dst`) with the uniform part
+// of the address in a scalar base and the lane part in a 32-bit byte offset: no vector address
+// arithmetic per load.  Issued from inline asm so that the compiler neither counts it nor orders LDS
+// reads behind it; callers wait with an explicit vmcnt.
+__device__ __forceinline__ void glds_b128(unsigned voff, uint64_t sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(sbase)
+        : "memory");
+}
+// 16-byte segment (of the 8 in a 64-reference chunk row) that lane `lane` fetches when the 32-byte
+// slots of a row are permuted by (row bit 1) | (row bit 3) << 1; row bit 3 is the parity `par` of the
+// instruction index
+__device__ __forceinline__ int perm_seg(int lane, int par) {
+    const int perm = ((lane >> 4) & 1) | (par << 1);
+    return ((((lane & 7) >> 1) ^ perm) << 1) | (lane & 1);
+}
+
 constexpr int kBQ = 256;             // queries per block
 constexpr int kBR = 64;              // references per chunk
 constexpr int kBThreads = 256;
@@ -708,20 +728,18 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     // explicit vmcnt(0) in front of the mid-chunk barrier.
     const int st_seg = (lane & 7) ^ (((lane >> 4) & 1) << 2);
     const int wq_u = __builtin_amdgcn_readfirstlane(wq);
-    const uint16_t *st_row = rb + (int64_t)(8 * wq_u * kSeg + (lane >> 3)) * nr;   // this lane's first row
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)rbuf;
+    const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
+    const unsigned lane_off = row_off + st_seg * 16;
     auto stage = [&](int64_t r0, int slot) {
-        const int64_t col = r0 + st_seg * 8;
-        const uint16_t *src = st_row + (col < rend ? col : 0);
+        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
+        unsigned voff = lane_off;
+        if (!full) voff = row_off + (r0 + st_seg * 8 < rend ? (unsigned)(r0 + st_seg * 8) * 2 : 0);
 #pragma unroll
         for (int e = 0; e < kSeg; ++e) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + (wq_u * kSeg + e) * 1024);
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(src + (int64_t)e * 8 * nr), "s"(dst)
-                : "memory");
+            const int id = wq_u * kSeg + e;              // rows [8 id, 8 id + 8)
+            const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
+            glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
         }
     };
     // norm entry of the chunk after next, parked in a register; the masking is applied when it is
@@ -940,22 +958,21 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     // 8 rows its instruction covers and fetches the segment whose 32-byte slot index is XORed
     // with (row bit 1) | (row bit 3) << 1; row bit 3 is the parity of the instruction index
     const int wq_u = __builtin_amdgcn_readfirstlane(wq);
-    const uint16_t *st_row = rb + (int64_t)(8 * wq_u * kSeg + (lane >> 3)) * nr;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)rbuf;
+    const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
+    const unsigned lane_off[2] = {row_off + perm_seg(lane, 0) * 16, row_off + perm_seg(lane, 1) * 16};
     auto stage = [&](int64_t r0, int slot) {
+        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
 #pragma unroll
         for (int e = 0; e < kSeg; ++e) {
-            const int perm = ((lane >> 4) & 1) | (((wq_u * kSeg + e) & 1) << 1);
-            const int seg = ((((lane & 7) >> 1) ^ perm) << 1) | (lane & 1);
-            const int64_t col = r0 + seg * 8;
-            const uint16_t *src = st_row + (int64_t)e * 8 * nr + (col < rend ? col : 0);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + (wq_u * kSeg + e) * 1024);
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(src), "s"(dst)
-                : "memory");
+            const int id = wq_u * kSeg + e;              // rows [8 id, 8 id + 8)
+            unsigned voff = lane_off[id & 1];
+            if (!full) {
+                const int64_t col = r0 + perm_seg(lane, id & 1) * 8;
+                voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+            }
+            const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
+            glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
         }
     };
     float pre_nh = 0.f;
@@ -1261,24 +1278,24 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
     // ---- reference chunks: LDS-direct loads, 8 rows x 128 B per instruction -----------------------
     const int wq_u = __builtin_amdgcn_readfirstlane(wq);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+    const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
+    const unsigned lane_off[2] = {row_off + perm_seg(lane, 0) * 16, row_off + perm_seg(lane, 1) * 16};
     auto stage = [&](int64_t r0, int slot) {
+        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             const uint16_t *img = (part ? rlo : rhi) + roff;
 #pragma unroll
             for (int e = 0; e < kPerWave; ++e) {
                 const int id = wq_u * kPerWave + e;                        // rows [8 id, 8 id + 8)
-                const int perm = ((lane >> 4) & 1) | ((id & 1) << 1);
-                const int seg = ((((lane & 7) >> 1) ^ perm) << 1) | (lane & 1);
-                const int64_t col = r0 + seg * 8;
-                const uint16_t *src = img + (int64_t)(8 * id + (lane >> 3)) * nr + (col < rend ? col : 0);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kSlot + part * kImg + id * 1024);
-                unsigned keep;
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                    : "=&s"(keep)
-                    : "v"(src), "s"(dst)
-                    : "memory");
+                unsigned voff = lane_off[id & 1];
+                if (!full) {
+                    const int64_t col = r0 + perm_seg(lane, id & 1) * 8;
+                    voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+                }
+                const uint64_t sbase =
+                    (uint64_t)img + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
+                glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kSlot + part * kImg + id * 1024));
             }
         }
     };
@@ -1945,7 +1962,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
-    const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0;
+    const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0 && nr < (1 << 27);   // 32-bit lane offsets
     p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && C <= 256;
     p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 128 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
