@@ -50,6 +50,9 @@ def parse():
                     help="f32 only: 'split' runs the filter pass on bfloat16 MFMAs over a hi/lo split of the "
                          "float32 inputs (same exact results)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step result all-gather")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' with ranks sharing one GPU rehearses the multi-rank "
+                         "code path on a single-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the bfloat16 side measurement of the f32 run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -351,8 +354,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -376,18 +383,31 @@ def main():
         x = torch.randn(b, c, g, g, device=dev, generator=gen)
         return (x / x.norm(dim=1, keepdim=True)).to(tdt).contiguous()
     q, r = feats(), feats()
-    gather = world > 1 and not args.no_gather
+    # gloo cannot all-gather device tensors: the rehearsal backend runs without the result exchange
+    gather = world > 1 and not args.no_gather and args.backend == "nccl"
     filt = args.filter if args.dtype == "f32" else "native"
+
+    pending = []                                    # result gathers of the previous step, still in flight
 
     def step():
         dist_, ind_ = pea.correspondence.dense_nn(q, r, args.k, filter=filt)
         if gather:
-            sharding.allgather_results(ind_, b * world)
-            sharding.allgather_results(dist_, b * world)
+            # the records of step i travel over xGMI while step i + 1 computes; every gather is
+            # completed inside the timed region (here or in drain())
+            for p_ in pending:
+                p_.wait()
+            pending[:] = [sharding.allgather_results_async(ind_, b * world),
+                          sharding.allgather_results_async(dist_, b * world)]
         return dist_, ind_
+
+    def drain():
+        for p_ in pending:
+            p_.wait()
+        pending.clear()
 
     for _ in range(args.warmup):
         step()
+    drain()
     _abi.check(_abi.lib.ispa_timing_enable(args.steps))
     if world > 1:
         dist.barrier()
@@ -395,6 +415,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -45,3 +45,38 @@ def allgather_results(local, total, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+class PendingGather:
+    """Result all-gather in flight (even shards): `wait()` returns the (total, ...) tensor.
+
+    The collective runs on the communicator's own stream, so kernels of the next batch launched
+    meanwhile overlap with it; the object keeps the input block alive until then."""
+
+    def __init__(self, work, out, local):
+        self._work, self._out, self._local = work, out, local
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = self._local = None
+        return self._out
+
+
+def allgather_results_async(local, total, group=None):
+    """Start the all-gather of this rank's result block and return a PendingGather.
+
+    Without a process group, or with uneven shards, the gather is done at once (the object is
+    already complete)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return PendingGather(None, allgather_results(local, total, group), None)
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(total, world)
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError("local block does not match this rank's shard")
+    if any(s != sizes[0] for s in sizes):
+        return PendingGather(None, allgather_results(local, total, group), None)
+    local = local.contiguous()
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+    return PendingGather(work, out, local)

@@ -40,6 +40,9 @@ def _worker(rank, world, port, total, q):
     full = torch.arange(total * 3, dtype=torch.int32).reshape(total, 3)
     got = sh.allgather_results(full[lo:hi].clone(), total)
     ok = torch.equal(got, full)
+    # overlapped form: two gathers in flight, collected in order
+    pend = [sh.allgather_results_async((full[lo:hi] + k).clone(), total) for k in (0, 5)]
+    ok = ok and torch.equal(pend[0].wait(), full) and torch.equal(pend[1].wait(), full + 5)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))
