@@ -192,6 +192,16 @@ int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int
 int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
                        int W, int grid, float *out, float *workspace, void *stream);
 
+/* `ExtractFeature` layer of the Caffe-UCN fork as the reference configures it (the producer of the KNN queries)
+ *   ucn_code/nets/train.prototxt:2116-2127 (num_coord_elements 5, coord_start_ind 0, downsampling_factor 4.0)
+ * feature (B,C,H,W) f32; coords (B,n,num_coord_elements) f32 rows with image (x, y) in columns
+ * coord_start_ind, +1; out (B,C,n) f32 = feature at (x, y) / downsampling: the cell (floor x, floor y) clamped
+ * to the map, or (bilinear != 0) the float32 interpolation of the four surrounding cells.  The layer's
+ * source is not part of the reference: the sampling rule is this library's contract. */
+int ispa_extract_feature(const float *feature, int B, int C, int H, int W, const float *coords, int64_t n,
+                         int num_coord_elements, int coord_start_ind, float downsampling, int bilinear,
+                         float *out, void *stream);
+
 /* proxy_renderer.proxy_render's lookup, batched
  *   classifier_code/train_test_scripts/utils/proxy_renderer.py:100-106 (argmin) and :138-151 (normalize)
  * view_params (n_view,3), stored (n_stored,3) f64 rows [azimuth, elevation, tilt] in degrees.

@@ -51,3 +51,35 @@ def nn_sgemm(q, r, k=1, index_base=1):
         idx = np.take_along_axis(part, np.argsort(sub, axis=1, kind="stable"), axis=1).T
     dist = np.take_along_axis(d2, idx.T, axis=1).T
     return (idx + index_base).astype(np.int32), dist
+
+
+def extract_feature(feature, coords, downsampling=4.0, coord_start_ind=0, mode="nearest"):
+    """`ExtractFeature` layer contract (ucn_code/nets/train.prototxt:2116-2127; external Caffe-UCN
+    layer, PARITY UNPINNED): sample feature (B,C,H,W) f32 at the image coordinates held in columns
+    coord_start_ind, coord_start_ind+1 (x, y) of coords (B,n,ncol), divided by the downsampling
+    factor as hard_negative_processing_layer.py:33-37 does.  mode "nearest": cell (floor(x), floor(y))
+    clamped to the map; "bilinear": float32 interpolation of the four surrounding cells (clamped),
+    value = (1-wy)*((1-wx)*f00 + wx*f01) + wy*((1-wx)*f10 + wx*f11).  Returns (B,C,n) f32."""
+    f = np.asarray(feature, dtype=np.float32)
+    c = np.asarray(coords, dtype=np.float32)
+    b, ch, h, w = f.shape
+    ds = np.float32(downsampling)
+    fx = c[:, :, coord_start_ind] / ds
+    fy = c[:, :, coord_start_ind + 1] / ds
+    x0f, y0f = np.floor(fx), np.floor(fy)
+    x0 = np.clip(x0f, 0, w - 1).astype(np.int64)
+    y0 = np.clip(y0f, 0, h - 1).astype(np.int64)
+    bi = np.arange(b)[:, None]
+    if mode == "nearest":
+        return np.ascontiguousarray(f[bi, :, y0, x0].transpose(0, 2, 1))
+    x1 = np.clip(x0f + 1, 0, w - 1).astype(np.int64)
+    y1 = np.clip(y0f + 1, 0, h - 1).astype(np.int64)
+    wx = (fx - x0f).astype(np.float32)[:, :, None]
+    wy = (fy - y0f).astype(np.float32)[:, :, None]
+    one = np.float32(1.0)
+    f00, f01 = f[bi, :, y0, x0], f[bi, :, y0, x1]
+    f10, f11 = f[bi, :, y1, x0], f[bi, :, y1, x1]
+    top = (one - wx) * f00 + wx * f01
+    bot = (one - wx) * f10 + wx * f11
+    out = (one - wy) * top + wy * bot
+    return np.ascontiguousarray(out.astype(np.float32).transpose(0, 2, 1))

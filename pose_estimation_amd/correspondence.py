@@ -71,6 +71,28 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native")
     return out
 
 
+def extract_feature(feature, correspondences, downsampling_factor=4.0, coord_start_ind=0, mode="nearest"):
+    """Query features for dense_nn, as the `ExtractFeature` layer in front of `KNN` produces them
+    (ucn_code/nets/train.prototxt:2116-2127): feature (B,C,H,W) sampled at image coordinates
+    correspondences[:, :, coord_start_ind : coord_start_ind + 2] / downsampling_factor -> (B,C,n) f32.
+    mode "nearest" (cell floor(x), floor(y)) or "bilinear"; the layer's own source is not in the
+    reference, so the sampling rule is this library's contract."""
+    if mode not in ("nearest", "bilinear"):
+        raise ValueError("mode must be 'nearest' or 'bilinear'")
+    as_tensor = dv.is_tensor(feature)
+    f = dv.to_dev(feature, torch.float32)
+    c = dv.to_dev(correspondences, torch.float32)
+    if f.dim() != 4 or c.dim() != 3 or c.shape[0] != f.shape[0] or c.shape[2] < coord_start_ind + 2:
+        raise ValueError("feature must be (B,C,H,W) and correspondences (B,n,>=coord_start_ind+2)")
+    b, ch, h, w = f.shape
+    n = c.shape[1]
+    out = dv.empty((b, ch, n), torch.float32)
+    _abi.check(_abi.lib.ispa_extract_feature(dv.ptr(f), b, ch, h, w, dv.ptr(c), n, c.shape[2], int(coord_start_ind),
+                                             float(downsampling_factor), int(mode == "bilinear"), dv.ptr(out),
+                                             dv.stream_ptr()))
+    return dv.back(out, as_tensor)
+
+
 def l2norm(x):
     """x (B,C,...) float32 -> x / sqrt(sum_c x^2); no epsilon, like the reference layer."""
     as_tensor = dv.is_tensor(x)

@@ -1,6 +1,7 @@
 // Consumers of the correspondence stage that the reference runs as numpy one-liners per item:
 //   proxy_renderer.py:100-106,138-151   nearest stored render to a requested pose
 //   hard_negative_processing_layer.py:44-58,188-190,218-234   1-NN index -> image coordinate -> PCK hit counts
+//   ucn_code/nets/train.prototxt:2116-2127   ExtractFeature: query features at the ground-truth coordinates
 // Batched here so that neither the stored-pose table nor the index maps leave the device.
 // Arithmetic follows numpy operation by operation (float64, separately rounded, sums left to right,
 // correctly rounded sqrt), so indices and counts are bit-exact.
@@ -100,7 +101,58 @@ __global__ __launch_bounds__(kThreads) void pck_counts_kernel(const int32_t *__r
     if (threadIdx.x < n_radii) counts[threadIdx.x * B + b] = hits[threadIdx.x];
 }
 
+// out[b][c][i] = feature[b][c] sampled at (x, y) = coords[b][i][start .. start+1] / downsampling.
+// One thread per (b, i); the channel loop walks a column of the (C, H*W) map (stride H*W), the
+// stores of a wave are contiguous along i.
+__global__ __launch_bounds__(kThreads) void extract_feature_kernel(const float *__restrict__ feature, int C, int H,
+                                                                    int W, const float *__restrict__ coords,
+                                                                    int64_t n, int ncol, int start, float ds,
+                                                                    int bilinear, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float *c = coords + ((int64_t)b * n + i) * ncol + start;
+    const float fx = c[0] / ds, fy = c[1] / ds;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    // clamp in float first: NaN and out-of-range coordinates land on an edge cell
+    const int x0 = (int)fminf(fmaxf(x0f, 0.f), (float)(W - 1)), y0 = (int)fminf(fmaxf(y0f, 0.f), (float)(H - 1));
+    const int x1 = (int)fminf(fmaxf(x0f + 1.f, 0.f), (float)(W - 1)), y1 = (int)fminf(fmaxf(y0f + 1.f, 0.f), (float)(H - 1));
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int64_t hw = (int64_t)H * W;
+    const float *f = feature + (int64_t)b * C * hw;
+    float *o = out + (int64_t)b * C * n + i;
+    for (int ch = 0; ch < C; ++ch, f += hw, o += n) {
+        if (!bilinear) {
+            *o = f[(int64_t)y0 * W + x0];
+        } else {
+            const float f00 = f[(int64_t)y0 * W + x0], f01 = f[(int64_t)y0 * W + x1];
+            const float f10 = f[(int64_t)y1 * W + x0], f11 = f[(int64_t)y1 * W + x1];
+            const float top = (1.f - wx) * f00 + wx * f01;      // separately rounded (no contraction)
+            const float bot = (1.f - wx) * f10 + wx * f11;
+            *o = (1.f - wy) * top + wy * bot;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ispa_extract_feature(const float *feature, int B, int C, int H, int W, const float *coords, int64_t n,
+                                    int num_coord_elements, int coord_start_ind, float downsampling, int bilinear,
+                                    float *out, void *stream) {
+    ISPA_REQUIRE(B >= 0 && n >= 0, "negative size");
+    ISPA_REQUIRE(C > 0 && H > 0 && W > 0, "feature map shape (%d,%d,%d) invalid", C, H, W);
+    ISPA_REQUIRE(coord_start_ind >= 0 && coord_start_ind + 2 <= num_coord_elements,
+                 "coordinate columns %d..%d outside the %d-element rows", coord_start_ind, coord_start_ind + 1,
+                 num_coord_elements);
+    ISPA_REQUIRE(downsampling > 0.f, "downsampling factor must be positive");
+    ISPA_REQUIRE(B <= 65535, "too many batch items per call (%d)", B);
+    if (B == 0 || n == 0) return ISPA_OK;
+    ISPA_REQUIRE(feature && coords && out, "null pointer");
+    hipLaunchKernelGGL(extract_feature_kernel, dim3(ispa::blocks_for(n, kThreads), B), dim3(kThreads), 0,
+                       (hipStream_t)stream, feature, C, H, W, coords, n, num_coord_elements, coord_start_ind,
+                       downsampling, bilinear, out);
+    return ispa::check_launch("extract_feature_kernel");
+}
 
 extern "C" int ispa_nearest_view(const double *view_params, int n_view, const double *stored, int n_stored,
                                  int32_t *index, double *distance, void *stream) {

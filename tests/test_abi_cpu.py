@@ -38,6 +38,8 @@ def test_argument_checks_do_not_need_a_gpu():
     rc = _abi.lib.ispa_pck_counts(1, 1, 1, 4, 1, 56, 4.0, 1, 1, 9, 1, None)
     assert rc == -1 and b"radii" in _abi.lib.ispa_last_error()
     assert _abi.lib.ispa_pck_counts(None, 0, 1, 0, None, 56, 4.0, 1, None, 0, None, None) == 0
+    rc = _abi.lib.ispa_extract_feature(1, 1, 8, 4, 4, 1, 10, 5, 4, 4.0, 0, 1, None)
+    assert rc == -1 and b"coordinate columns" in _abi.lib.ispa_last_error()
 
 
 def test_host_helpers_without_gpu():

@@ -613,6 +613,30 @@ def test_nearest_view_matches_numpy(pea):
         pea.correspondence.nearest_view([0, 0, 0], np.zeros((0, 3)))
 
 
+def test_extract_feature_then_knn(pea):
+    from oracle import nn as onn
+    rs = np.random.RandomState(29)
+    f1 = _unit(rs, (3, 128, 56, 56))
+    f2 = _unit(rs, (3, 128, 56, 56))
+    corr = np.concatenate([rs.uniform(-6, 230, (3, 300, 4)), np.ones((3, 300, 1))], axis=2).astype(np.float32)
+    corr[0, 0, :2] = [0.0, 0.0]
+    corr[0, 1, :2] = [223.0, 223.0]
+    corr[0, 2, :2] = [223.9, 4.0]                     # x1 clamps at the right edge
+    corr[0, 3, :2] = [8.0, 12.0]                      # exactly on a cell
+    for mode in ("nearest", "bilinear"):
+        got = pea.correspondence.extract_feature(f1, corr, mode=mode)
+        assert got.shape == (3, 128, 300) and got.dtype == np.float32
+        assert np.array_equal(got, onn.extract_feature(f1, corr, mode=mode)), mode      # bit-exact float32
+    # other column layout, as num_coord_elements / coord_start_ind allow
+    got = pea.correspondence.extract_feature(f2, corr, coord_start_ind=2, mode="bilinear")
+    assert np.array_equal(got, onn.extract_feature(f2, corr, coord_start_ind=2, mode="bilinear"))
+    # the layer pair of train.prototxt: extract queries from image 1, match them in image 2
+    qf = pea.correspondence.extract_feature(f1, corr)
+    _nn_check(pea, qf, f2.reshape(3, 128, -1), 1)
+    with pytest.raises(ValueError):
+        pea.correspondence.extract_feature(f1, corr[:, :, :1])
+
+
 def test_pck_counts_match_numpy(pea):
     import torch
     rs = np.random.RandomState(23)

@@ -234,3 +234,19 @@ def test_filename_codec_and_keypoints(golden_geometry):
     assert xy[0, 0].tolist() == [[0, 0], [0, 4], [220, 220]]
     params = np.array([[0, 10, 0], [350, 0, 0], [120, 10, 0], [10, 80, 0]], dtype=np.float64)
     assert kp.nearest_view([355, 0, 0], params) == 1 and kp.nearest_view([2, 9, 0], params) == 0
+
+
+def test_extract_feature_known_answers():
+    from oracle import nn as onn
+    c, h, w = 3, 6, 7
+    f = (100.0 * np.arange(c)[:, None, None] + 10.0 * np.arange(h)[None, :, None] + np.arange(w)[None, None, :])
+    f = f[None].astype(np.float32)
+    coords = np.array([[[8.0, 12.0, 0, 0, 1], [10.0, 14.0, 0, 0, 1], [-3.0, 100.0, 0, 0, 1]]], dtype=np.float32)
+    near = onn.extract_feature(f, coords)
+    assert near.shape == (1, 3, 3)
+    assert np.array_equal(near[0, :, 0], [32.0, 132.0, 232.0])          # cell (x=2, y=3)
+    assert np.array_equal(near[0, :, 1], [32.0, 132.0, 232.0])          # floor(2.5), floor(3.5)
+    assert np.array_equal(near[0, :, 2], [50.0, 150.0, 250.0])          # clamped to (x=0, y=5)
+    bil = onn.extract_feature(f, coords, mode="bilinear")
+    assert np.array_equal(bil[0, :, 0], [32.0, 132.0, 232.0])
+    assert np.array_equal(bil[0, :, 1], [37.5, 137.5, 237.5])           # a linear ramp is reproduced exactly
