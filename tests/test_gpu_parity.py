@@ -490,6 +490,33 @@ def test_nn_bf16_shapes_and_error_model(pea):
                 assert worst <= 0.5, worst
 
 
+def test_nn_bf16_against_float32_oracle(pea):
+    """bfloat16 features vs the float32 oracle on the unrounded features: wherever the float32 margin
+    (d2 - d1) / max(d1, 1e-6) exceeds 2^-7 the nearest neighbour must be the same; distances within
+    1e-2 relative (plus 1e-2 absolute for near-zero distances).  The mismatch rate elsewhere is printed."""
+    import torch
+    rs = np.random.RandomState(53)
+    q = _unit(rs, (4, 128, 1024))
+    r = _unit(rs, (4, 128, 4096))
+    # a slice of easy, well separated matches: noisy copies of references
+    q[:, :, :256] = r[:, :, 100:356] + 0.02 * rs.randn(4, 128, 256).astype(np.float32)
+    dist, ind = pea.correspondence.dense_nn(torch.from_numpy(q).cuda().to(torch.bfloat16),
+                                            torch.from_numpy(r).cuda().to(torch.bfloat16), 1)
+    dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
+    checked = mismatched = 0
+    for i in range(4):
+        want_i, want_d = cnative.nn_exact(q[i], r[i], 2, 1)
+        margin = (want_d[1] - want_d[0]) / np.maximum(want_d[0], 1e-6)
+        sure = margin > 2.0 ** -7
+        assert np.array_equal(ind[i, 0][sure], want_i[0][sure])
+        checked += int(sure.sum())
+        mismatched += int((ind[i, 0][~sure] != want_i[0][~sure]).sum())
+        assert np.all(np.abs(dist[i, 0] - want_d[0]) <= 1e-2 * np.abs(want_d[0]) + 1e-2)
+    assert checked >= 4 * 256
+    print(f"bf16 vs float32 oracle: {checked} of 4096 queries above the 2^-7 margin all agree; "
+          f"{mismatched} of the other {4096 - checked} differ")
+
+
 def test_nn_split_filter(pea):
     """float32 inputs through the split-bfloat16 filter: same exact indices as the float32 path."""
     rs = np.random.RandomState(41)
