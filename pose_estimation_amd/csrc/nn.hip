@@ -146,9 +146,9 @@ struct TagTop1 {
     float a, b, a_before, pinf;
     int half, cur;
     __device__ __forceinline__ void init() {
-        a = b = kNegInf;
+        a = b = a_before = kNegInf;
         half = -1;
-        cur = 0;
+        cur = -1;
         // +inf in a register the optimiser cannot see through: med3(a, t, +inf) then stays ONE
         // v_med3_f32 instead of a canonicalising v_max pair
         pinf = __builtin_inff();
@@ -178,6 +178,36 @@ struct TagTop1 {
     __device__ __forceinline__ void push2_end() {
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(t1), "v"(t2));
         asm("v_max_f32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(mid));
+    }
+    // Four scores in nine instructions, in four slices a caller can place between different MFMAs:
+    // with m1 = med3(a, t1, t2), a' = max3(a, t1, t2), m2 = med3(a', t3, t4), a'' = max3(a', t3, t4) the
+    // new runner-up is max3(b, m1, m2).
+    float mid2;
+    __device__ __forceinline__ float tagged(float x, int tag) const {
+        return __uint_as_float((__float_as_uint(x) & 0xfffffff0u) | (unsigned)tag);
+    }
+    template <typename V>
+    __device__ __forceinline__ void push4_step(int step, const V &x, int tag0, int off = 0) {
+        if (step == 0) {
+            t1 = tagged(x[off], tag0);
+            t2 = tagged(x[off + 1], tag0 + 1);
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(mid) : "v"(a), "v"(t1), "v"(t2));
+        } else if (step == 1) {
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(t1), "v"(t2));
+            t1 = tagged(x[off + 2], tag0 + 2);
+        } else if (step == 2) {
+            t2 = tagged(x[off + 3], tag0 + 3);
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(mid2) : "v"(a), "v"(t1), "v"(t2));
+        } else {
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(t1), "v"(t2));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(mid), "v"(mid2));
+        }
+    }
+    // x[off .. off+3] with tags tag0 .. tag0+3
+    template <typename V>
+    __device__ __forceinline__ void push4(const V &x, int tag0, int off = 0) {
+#pragma unroll
+        for (int step = 0; step < 4; ++step) push4_step(step, x, tag0, off);
     }
     __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
     __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
@@ -383,15 +413,15 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
             for (int ri = 0; ri < 2; ++ri) {
                 best[qi].begin_half(chunk * 2 + ri);
 #pragma unroll
-                for (int reg = 0; reg < 16; reg += 2) {
+                for (int reg = 0; reg < 16; reg += 4) {
                     if (ISPA_ABLATE == 4 || ISPA_ABLATE == 6) {
-                        asm volatile("" ::"v"(acc[ri][qi][reg]), "v"(acc[ri][qi][reg + 1]));
+                        asm volatile("" ::"v"(acc[ri][qi][reg]), "v"(acc[ri][qi][reg + 1]), "v"(acc[ri][qi][reg + 2]),
+                                     "v"(acc[ri][qi][reg + 3]));
                     } else if constexpr (K == 1) {
-                        best[qi].push2_begin(acc[ri][qi][reg], reg, acc[ri][qi][reg + 1], reg + 1);
-                        best[qi].push2_end();
+                        best[qi].push4(acc[ri][qi], reg, reg);
                     } else {
-                        best[qi].push(acc[ri][qi][reg], reg);
-                        best[qi].push(acc[ri][qi][reg + 1], reg + 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) best[qi].push(acc[ri][qi][reg + e], reg + e);
                     }
                 }
                 best[qi].end_half();
@@ -575,13 +605,12 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
             for (int ri = 0; ri < 2; ++ri) {
                 best[qi].begin_half(chunk * 2 + ri);
 #pragma unroll
-                for (int reg = 0; reg < 16; reg += 2) {
+                for (int reg = 0; reg < 16; reg += 4) {
                     if constexpr (K == 1) {
-                        best[qi].push2_begin(acc[ri][qi][reg], reg, acc[ri][qi][reg + 1], reg + 1);
-                        best[qi].push2_end();
+                        best[qi].push4(acc[ri][qi], reg, reg);
                     } else {
-                        best[qi].push(acc[ri][qi][reg], reg);
-                        best[qi].push(acc[ri][qi][reg + 1], reg + 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) best[qi].push(acc[ri][qi][reg + e], reg + e);
                     }
                 }
                 best[qi].end_half();
@@ -1025,13 +1054,18 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
             asm volatile("" : "+v"(acc_b[rt][qt]));     // opaque: keeps the loop from being peeled
         }
 
-    // MFMAs of half-step (`rimg`, `ri`) into `now`; top-list update of `prev` (half-step prev_half)
-    // interleaved one score per MFMA.  a[0..1] hold the two reference-tile fragments of k-step 0 on
-    // entry and those of the next half-step on exit.
+    // MFMAs of half-step (`rimg`, `ri`) into `now`; top-list update of `prev` (half-step prev_ri of
+    // chunk prev_chunk) interleaved one score per MFMA, four scores of one query tile at a time.  The
+    // tag is the position within the CHUNK (prev_ri * 8 + tile * 4 + register), so which chunk gave
+    // the best score is tracked once per chunk.  a[0..1] hold the two reference-tile fragments of
+    // k-step 0 on entry and those of the next half-step on exit.
     auto half_step = [&](const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 (&a)[2],
-                         const f32x4 (&init)[2], f32x4 (&now)[2][4], const f32x4 (&prev)[2][4], int prev_half) {
+                         const f32x4 (&init)[2], f32x4 (&now)[2][4], const f32x4 (&prev)[2][4], int prev_chunk,
+                         int prev_ri) {
+        if (prev_ri == 0) {
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) best[qt].begin_half(prev_half);
+            for (int qt = 0; qt < 4; ++qt) best[qt].begin_half(prev_chunk);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS32; ++ks) {
             bf16x8 an[2];
@@ -1053,20 +1087,15 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
                     // 32 scores per half-step spread over its 8 * KS32 MFMAs
                     constexpr int per = 4 / KS32 > 0 ? 4 / KS32 : 1;
                     const int m = (ks * 8 + rt * 4 + qt) * per;     // scores [m, m+per) of the previous half-step
-                    // scores 2j and 2j+1 belong to the same query tile and are pushed as a pair
 #pragma unroll
                     for (int e = 0; e < per; ++e) {
                         const int sc = m + e;
                         if (sc < 32) {
                             const int prt = sc >> 4, pqt = (sc >> 2) & 3, reg = sc & 3;
-                            if (ISPA_ABLATE == 1 || ISPA_ABLATE == 13 || ISPA_ABLATE == 123) {
+                            if (ISPA_ABLATE == 1 || ISPA_ABLATE == 13 || ISPA_ABLATE == 123)
                                 asm volatile("" ::"v"(prev[prt][pqt][reg]));
-                            } else if (!(sc & 1)) {
-                                best[pqt].push2_begin(prev[prt][pqt][reg], prt * 4 + reg, prev[prt][pqt][reg + 1],
-                                                      prt * 4 + reg + 1);
-                            } else {
-                                best[pqt].push2_end();
-                            }
+                            else
+                                best[pqt].push4_step(reg, prev[prt][pqt], prev_ri * 8 + prt * 4);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one MFMA, then its share of the vector work
@@ -1076,14 +1105,13 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         }
         if (KS32 == 3) {                                 // 24 MFMAs covered 24 scores: the rest here
 #pragma unroll
-            for (int sc = 24; sc < 32; sc += 2) {
-                best[(sc >> 2) & 3].push2_begin(prev[sc >> 4][(sc >> 2) & 3][sc & 3], (sc >> 4) * 4 + (sc & 3),
-                                                prev[sc >> 4][(sc >> 2) & 3][(sc & 3) + 1], (sc >> 4) * 4 + (sc & 3) + 1);
-                best[(sc >> 2) & 3].push2_end();
-            }
+            for (int sc = 24; sc < 32; sc += 4)
+                best[(sc >> 2) & 3].push4(prev[sc >> 4][(sc >> 2) & 3], prev_ri * 8 + (sc >> 4) * 4);
         }
+        if (prev_ri == 1) {
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) best[qt].end_half();
+            for (int qt = 0; qt < 4; ++qt) best[qt].end_half();
+        }
     };
 
     bf16x8 a[2];
@@ -1102,7 +1130,7 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         const char *next_img = rbuf + next_slot * kRBuf;
         const f32x4 init_b[2] = {load_init(nhbuf + slot * kBR, 1, 0), load_init(nhbuf + slot * kBR, 1, 1)};
         __builtin_amdgcn_sched_barrier(0);
-        half_step(rimg, 0, rimg, 1, a, init_a, acc_a, acc_b, chunk * 2 - 1);
+        half_step(rimg, 0, rimg, 1, a, init_a, acc_a, acc_b, chunk - 1, 1);
         nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1111,18 +1139,15 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         init_a[0] = load_init(nhbuf + next_slot * kBR, 0, 0);
         init_a[1] = load_init(nhbuf + next_slot * kBR, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk * 2);
+        half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk, 0);
         slot = next_slot;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
-    if (nchunks > 0) {
+    if (nchunks > 0) {                                   // second half of the last chunk
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            best[qt].begin_half(nchunks * 2 - 1);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) best[qt].push(acc_b[rt][qt][reg], rt * 4 + reg);
+            for (int rt = 0; rt < 2; ++rt) best[qt].push4(acc_b[rt][qt], 8 + rt * 4);
             best[qt].end_half();
         }
     }
@@ -1138,9 +1163,9 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         for (int sl = 0; sl <= 1; ++sl) {
             const int code = best[qt].code(sl);
             int ref = -1;
-            if (code >= 0) {                             // code = half-step * 16 + (tile * 4 + reg)
+            if (code >= 0) {                             // code = chunk * 16 + (half-step * 8 + tile * 4 + reg)
                 const int tag = code & 15;
-                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (tag >> 2) * 16 + 4 * g + (tag & 3));
+                ref = (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
             }
             const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
             part_val[o] = best[qt].value(sl);
@@ -1343,9 +1368,11 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
     // MFMAs of half-step `ri` of the slot at `img` into `now` (3 per tile and k-step); the top-list
     // update of `prev` (half-step prev_half) is spread over them, one score per three MFMAs.
     auto half_step = [&](const char *img, int ri, const f32x4 (&init)[2], f32x4 (&now)[2][2],
-                         const f32x4 (&prev)[2][2], int prev_half) {
-        best[0].begin_half(prev_half);
-        best[1].begin_half(prev_half);
+                         const f32x4 (&prev)[2][2], int prev_chunk, int prev_ri) {
+        if (prev_ri == 0) {                              // the best score's chunk is tracked once per chunk
+            best[0].begin_half(prev_chunk);
+            best[1].begin_half(prev_chunk);
+        }
         bf16x8 ah[2], al[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -1374,12 +1401,8 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
 #pragma unroll
                     for (int e = 0; e < per; ++e) {
                         const int sc = m + e;
-                        if (sc < 16) {                   // scores 2j, 2j+1 as a pair (same query tile)
-                            auto &bl = best[(sc >> 2) & 1];
-                            const f32x4 &pv = prev[sc >> 3][(sc >> 2) & 1];
-                            if (!(sc & 1)) bl.push2_begin(pv[sc & 3], (sc >> 3) * 4 + (sc & 3), pv[(sc & 3) + 1], (sc >> 3) * 4 + (sc & 3) + 1);
-                            else bl.push2_end();
-                        }
+                        if (sc < 16)                     // four scores of one query tile at a time
+                            best[(sc >> 2) & 1].push4_step(sc & 3, prev[sc >> 3][(sc >> 2) & 1], prev_ri * 8 + (sc >> 3) * 4);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1391,14 +1414,13 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
         }
         if (KS32 == 3) {
 #pragma unroll
-            for (int sc = 12; sc < 16; sc += 2) {
-                best[(sc >> 2) & 1].push2_begin(prev[sc >> 3][(sc >> 2) & 1][sc & 3], (sc >> 3) * 4 + (sc & 3),
-                                                prev[sc >> 3][(sc >> 2) & 1][(sc & 3) + 1], (sc >> 3) * 4 + (sc & 3) + 1);
-                best[(sc >> 2) & 1].push2_end();
-            }
+            for (int sc = 12; sc < 16; sc += 4)
+                best[(sc >> 2) & 1].push4(prev[sc >> 3][(sc >> 2) & 1], prev_ri * 8 + (sc >> 3) * 4);
         }
-        best[0].end_half();
-        best[1].end_half();
+        if (prev_ri == 1) {
+            best[0].end_half();
+            best[1].end_half();
+        }
     };
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1407,8 +1429,8 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
         const float *nh = nhbuf + slot * kBR;
         const f32x4 init_a[2] = {load_init(nh, 0, 0), load_init(nh, 0, 1)};
         const f32x4 init_b[2] = {load_init(nh, 1, 0), load_init(nh, 1, 1)};
-        half_step(img, 0, init_a, acc_a, acc_b, chunk * 2 - 1);
-        half_step(img, 1, init_b, acc_b, acc_a, chunk * 2);
+        half_step(img, 0, init_a, acc_a, acc_b, chunk - 1, 1);
+        half_step(img, 1, init_b, acc_b, acc_a, chunk, 0);
         // chunk end: the next chunk's images (requested a chunk ago) must have landed, and this slot
         // must be free of readers before it is refilled
         nhbuf[(slot ^ 1) * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
@@ -1420,12 +1442,9 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            best[qt].begin_half(nchunks * 2 - 1);
+        for (int qt = 0; qt < 2; ++qt) {               // second half of the last chunk
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) best[qt].push(acc_b[rt][qt][reg], rt * 4 + reg);
+            for (int rt = 0; rt < 2; ++rt) best[qt].push4(acc_b[rt][qt], 8 + rt * 4);
             best[qt].end_half();
         }
     }
@@ -1442,7 +1461,7 @@ __global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
             int ref = -1;
             if (code >= 0) {
                 const int tag = code & 15;
-                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (tag >> 2) * 16 + 4 * g + (tag & 3));
+                ref = (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
             }
             const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
             part_val[o] = best[qt].value(sl);
