@@ -517,6 +517,33 @@ def test_nn_bf16_against_float32_oracle(pea):
           f"{mismatched} of the other {4096 - checked} differ")
 
 
+def test_nn_randomised_shapes_all_paths(pea):
+    """Seeded sweep over shapes that select every filter variant (query-resident / LDS-staged float32,
+    16x16x32 and 32x32x16 bfloat16 with one or two blocks per CU, split, converting loader), with one
+    or several reference splits, ragged tiles and k up to 8, each checked against the oracle."""
+    rs = np.random.RandomState(2024)
+    channels = [8, 24, 32, 48, 64, 96, 128, 160, 192, 224, 256, 272]
+    cases = 0
+    for trial in range(48):
+        c = channels[trial % len(channels)]
+        b = int(rs.randint(1, 4))
+        # multiples of 8 most of the time (fast paths), sometimes of 4 or odd (guarded loaders)
+        unit = (8, 8, 8, 4, 1)[int(rs.randint(0, 5))]
+        nq = max(unit, int(rs.randint(1, 700)) // unit * unit)
+        nr = max(unit, int(rs.randint(1, 3000)) // unit * unit)
+        if trial % 6 == 0:
+            nq, nr = 8 * int(rs.randint(1, 20)), 8 * int(rs.randint(600, 1200))     # few queries: split references
+        k = (1, 1, 5, 8, 2, 1)[trial % 6]
+        mode = ("f32", "bf16", "split")[trial % 3]
+        q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
+        if trial % 5 == 0:                    # a few exact duplicates
+            r[:, :, nr // 2] = r[:, :, 0]
+            q[:, :, 0] = r[:, :, 0]
+        _nn_check(pea, q, r, k, bf16=(mode == "bf16"), split=(mode == "split"), index_base=trial % 2)
+        cases += 1
+    assert cases == 48
+
+
 def test_nn_split_filter(pea):
     """float32 inputs through the split-bfloat16 filter: same exact indices as the float32 path."""
     rs = np.random.RandomState(41)
