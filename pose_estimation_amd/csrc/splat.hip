@@ -186,15 +186,18 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             if (i >= n) continue;
             double u, v, z;
             project_point(P1, px[e], py[e], pz[e], u, v, z);
-            if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
-            if (!crop_apply(cx, tall, 1, u, v)) continue;
+            // crop and band membership first: only a point that can write into this band pays for
+            // the depth gather (each point is then gathered by one band's block, not by both)
+            double uc = u, vc = v;
+            if (!crop_apply(cx, tall, 1, uc, vc)) continue;
             int iu, iv;
-            if (!to_int(u, iu) || !to_int(v, iv)) continue;
+            if (!to_int(uc, iu) || !to_int(vc, iv)) continue;
             int y0, y1, x0, x1;
             py_slice(iv, spread, side, y0, y1);
             y0 = max(y0, row0);
             y1 = min(y1, row1);
             if (y0 >= y1) continue;
+            if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
             py_slice(iu, spread, side, x0, x1);
             const int tag = (int)i + 1;
             for (int y = y0; y < y1; ++y)
