@@ -38,6 +38,30 @@ __device__ __forceinline__ bool to_int(double x, int &out) {
     return true;
 }
 
+// A point's block [c-r : c+r] x [c'-r : c'+r] is a (2r x 2r) window that may be cut at either end of
+// the axis.  With side >= 2r every non-empty Python slice [lo, hi) is such a window anchored at
+// `anchor` = lo when it is cut at the far end (hi == size), hi - 2r otherwise (possibly negative: cut
+// at 0), i.e. it covers [anchor, anchor + 2r) intersected with [0, size).  So "highest point index
+// covering a pixel" = maximum over the 2r x 2r anchors up and left of the pixel: ONE atomic per point
+// on an anchor image, then a window maximum per pixel, instead of (2r)^2 atomics per point.
+__device__ __forceinline__ bool slice_anchor(int c, int r, int size, int &anchor) {
+    int lo, hi;
+    py_slice(c, r, size, lo, hi);
+    if (lo >= hi) return false;
+    anchor = hi == size ? lo : hi - 2 * r;
+    return true;
+}
+// window maximum for pixel (ly, x) of a band whose anchor image `img` has rows starting 2r-1 anchors
+// above the band's first row and `pw` = side + 2r - 1 columns starting 2r-1 anchors left of column 0
+__device__ __forceinline__ int window_owner(const int *img, int pw, int ly, int x, int w) {
+    int o = 0;
+    for (int dr = 0; dr < w; ++dr) {
+        const int *row = img + (ly + w - 1 - dr) * pw + x + w - 1;
+        for (int dc = 0; dc < w; ++dc) o = max(o, row[-dc]);
+    }
+    return o;
+}
+
 __global__ __launch_bounds__(kThreads) void flow_owner_kernel(const double *__restrict__ uv1,
                                                               const uint8_t *__restrict__ truth, int64_t n,
                                                               int spread, int side,
@@ -82,7 +106,10 @@ __global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__
 // resolves its band and writes the flow rows.  No global atomics, no scratch image in HBM.
 constexpr int kBandPixels = 25088;   // 98 KiB owner band (half of a 224 x 224 map): one block per CU
 constexpr int kBandThreads = 1024;
+constexpr int kMaxDilateSpread = 4;          // window maximum over at most 8 x 8 anchors per pixel
+constexpr int kMaxBandLds = 150 * 1024;      // bytes of dynamic LDS a band kernel may ask for
 
+template <bool DILATE>
 __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *__restrict__ uv1,
                                                                  const double *__restrict__ uv2,
                                                                  const uint8_t *__restrict__ truth, int64_t n,
@@ -93,7 +120,9 @@ __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *_
     const int row0 = blockIdx.x * band_rows;
     const int row1 = min(row0 + band_rows, side);
     const int npix = (row1 - row0) * side;
-    for (int p = threadIdx.x; p < npix; p += kBandThreads) owner[p] = 0;
+    const int w = 2 * spread, pw = side + w - 1;         // DILATE: anchor image (band rows + w - 1) x pw
+    const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
+    for (int p = threadIdx.x; p < nimg; p += kBandThreads) owner[p] = 0;
     __syncthreads();
     const double *a = uv1 + (int64_t)m * 3 * n;
     const double *b = uv2 + (int64_t)m * 3 * n;
@@ -120,21 +149,29 @@ __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *_
             if (!keep[e]) continue;
             int u, v;
             if (!to_int(pu[e], u) || !to_int(pv[e], v)) continue;
-            int y0, y1, x0, x1;
-            py_slice(v, spread, side, y0, y1);
-            y0 = max(y0, row0);
-            y1 = min(y1, row1);
-            if (y0 >= y1) continue;
-            py_slice(u, spread, side, x0, x1);
             const int tag = (int)(base + (int64_t)e * kBandThreads + threadIdx.x) + 1;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+            if (DILATE) {
+                int ry, cx;
+                if (!slice_anchor(v, spread, side, ry) || !slice_anchor(u, spread, side, cx)) continue;
+                const int lr = ry - (row0 - (w - 1));
+                if (lr < 0 || ry >= row1) continue;
+                atomicMax(&owner[lr * pw + cx + w - 1], tag);
+            } else {
+                int y0, y1, x0, x1;
+                py_slice(v, spread, side, y0, y1);
+                y0 = max(y0, row0);
+                y1 = min(y1, row1);
+                if (y0 >= y1) continue;
+                py_slice(u, spread, side, x0, x1);
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+            }
         }
     }
     __syncthreads();
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     for (int p = threadIdx.x; p < npix; p += kBandThreads) {
-        const int o = owner[p];
+        const int o = DILATE ? window_owner(owner, pw, p / side, p % side, w) : owner[p];
         double2 val = make_double2(0.0, 0.0);
         if (o > 0) {
             const int64_t i = o - 1;
@@ -150,6 +187,7 @@ __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *_
 // keep per band pixel the highest visible point index (LDS atomicMax); then, per owned pixel,
 // re-project the owning point at both poses and write the flow.  Nothing but the flow map goes to
 // HBM: the projected coordinates of the un-fused path (49 bytes per point and pose) never exist.
+template <bool DILATE>
 __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
     const float *__restrict__ depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
@@ -161,7 +199,9 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     const int row0 = blockIdx.x * band_rows;
     const int row1 = min(row0 + band_rows, side);
     const int npix = (row1 - row0) * side;
-    for (int p = threadIdx.x; p < npix; p += kBandThreads) owner[p] = 0;
+    const int w = 2 * spread, pw = side + w - 1;         // DILATE: anchor image (band rows + w - 1) x pw
+    const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
+    for (int p = threadIdx.x; p < nimg; p += kBandThreads) owner[p] = 0;
     __syncthreads();
     const double *P1 = cams1 + 12 * (int64_t)m;
     const double *P2 = cams2 + 12 * (int64_t)m;
@@ -192,22 +232,31 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             if (!crop_apply(cx, tall, 1, uc, vc)) continue;
             int iu, iv;
             if (!to_int(uc, iu) || !to_int(vc, iv)) continue;
-            int y0, y1, x0, x1;
-            py_slice(iv, spread, side, y0, y1);
-            y0 = max(y0, row0);
-            y1 = min(y1, row1);
-            if (y0 >= y1) continue;
-            if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
-            py_slice(iu, spread, side, x0, x1);
             const int tag = (int)i + 1;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+            if (DILATE) {
+                int ry, cx;
+                if (!slice_anchor(iv, spread, side, ry) || !slice_anchor(iu, spread, side, cx)) continue;
+                const int lr = ry - (row0 - (w - 1));
+                if (lr < 0 || ry >= row1) continue;
+                if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
+                atomicMax(&owner[lr * pw + cx + w - 1], tag);
+            } else {
+                int y0, y1, x0, x1;
+                py_slice(iv, spread, side, y0, y1);
+                y0 = max(y0, row0);
+                y1 = min(y1, row1);
+                if (y0 >= y1) continue;
+                if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
+                py_slice(iu, spread, side, x0, x1);
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+            }
         }
     }
     __syncthreads();
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     for (int p = threadIdx.x; p < npix; p += kBandThreads) {
-        const int o = owner[p];
+        const int o = DILATE ? window_owner(owner, pw, p / side, p % side, w) : owner[p];
         double2 val = make_double2(0.0, 0.0);
         if (o > 0) {
             const int64_t i = o - 1;
@@ -317,14 +366,18 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
         ISPA_REQUIRE(n == 0 || (uv1 && uv2 && truth), "null pointer");
         const int band_rows = kBandPixels / side;
         const int nbands = (side + band_rows - 1) / band_rows;
-        const size_t lds_bytes = (size_t)band_rows * side * sizeof(int);
-        static unsigned long long configured = 0;
-        if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&flow_band_kernel),
-                                             kBandPixels * (int)sizeof(int), &configured))
+        // small windows: one atomic per point on an anchor image + a window maximum per pixel
+        const size_t dilate_bytes = (size_t)(band_rows + 2 * spread - 1) * (side + 2 * spread - 1) * sizeof(int);
+        const bool dilate = spread >= 1 && spread <= kMaxDilateSpread && side >= 2 * spread && dilate_bytes <= kMaxBandLds;
+        const size_t lds_bytes = dilate ? dilate_bytes : (size_t)band_rows * side * sizeof(int);
+        static unsigned long long configured[2] = {0, 0};
+        if (int rc = ispa::allow_dynamic_lds(dilate ? reinterpret_cast<const void *>(&flow_band_kernel<true>)
+                                                    : reinterpret_cast<const void *>(&flow_band_kernel<false>),
+                                             kMaxBandLds, &configured[dilate]))
             return rc;
         const ispa::TimingSlot timed = ispa::timing_begin(s);
-        hipLaunchKernelGGL(flow_band_kernel, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, uv1, uv2, truth,
-                           n, spread, side, band_rows, flow);
+        hipLaunchKernelGGL(dilate ? flow_band_kernel<true> : flow_band_kernel<false>, dim3(nbands, n_map),
+                           dim3(kBandThreads), lds_bytes, s, uv1, uv2, truth, n, spread, side, band_rows, flow);
         ispa::timing_end(timed, s);
         return ispa::check_launch("flow_band_kernel");
     }
@@ -412,14 +465,18 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
     const int side = (int)ispa_geom::kCropSide;
     const int band_rows = kBandPixels / side;
     const int nbands = (side + band_rows - 1) / band_rows;
-    static unsigned long long configured = 0;
-    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&make_disparity_kernel),
-                                         kBandPixels * (int)sizeof(int), &configured))
+    const size_t dilate_bytes = (size_t)(band_rows + 2 * spread - 1) * (side + 2 * spread - 1) * sizeof(int);
+    const bool dilate = spread >= 1 && spread <= kMaxDilateSpread && dilate_bytes <= kMaxBandLds;
+    const size_t lds_bytes = dilate ? dilate_bytes : (size_t)band_rows * side * sizeof(int);
+    static unsigned long long configured[2] = {0, 0};
+    if (int rc = ispa::allow_dynamic_lds(dilate ? reinterpret_cast<const void *>(&make_disparity_kernel<true>)
+                                                : reinterpret_cast<const void *>(&make_disparity_kernel<false>),
+                                         kMaxBandLds, &configured[dilate]))
         return rc;
     const ispa::TimingSlot timed = ispa::timing_begin(s);
-    hipLaunchKernelGGL(make_disparity_kernel, dim3(nbands, n_map), dim3(kBandThreads),
-                       (size_t)band_rows * side * sizeof(int), s, pts, n, cams1, cams2, depth, depth_per_map, H, W,
-                       ylim, xlim, relax, crop, crop_per_map, spread, band_rows, flow);
+    hipLaunchKernelGGL(dilate ? make_disparity_kernel<true> : make_disparity_kernel<false>, dim3(nbands, n_map),
+                       dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, depth, depth_per_map, H, W, ylim, xlim,
+                       relax, crop, crop_per_map, spread, band_rows, flow);
     ispa::timing_end(timed, s);
     return ispa::check_launch("make_disparity_kernel");
 }

@@ -269,6 +269,27 @@ def test_flow_splat_slice_semantics(pea):
     assert empty.shape == (224, 224, 2) and not empty.any()
 
 
+@pytest.mark.parametrize("spread,side", [(1, 224), (2, 224), (3, 224), (4, 224), (5, 224), (2, 64), (4, 9), (2, 3)])
+def test_flow_splat_wild_coordinates(pea, spread, side):
+    """Coordinates far outside the map, on every border and negative (Python slices wrap): the
+    anchor-image path (spread <= 4) and the per-pixel atomic path must both match the literal loop."""
+    rs = np.random.RandomState(100 * spread + side)
+    n = 4000
+    uv = np.stack([rs.randint(-2 * side - 9, 2 * side + 9, n), rs.randint(-2 * side - 9, 2 * side + 9, n),
+                   np.ones(n)]).astype(np.float64)
+    uv[:2, :600] = rs.randint(-2 * spread - 1, 2 * spread + 2, (2, 600))              # around the origin
+    uv[:2, 600:1200] = side + rs.randint(-2 * spread - 1, 2 * spread + 2, (2, 600))   # around the far corner
+    uv[:2, 1200:1800] = -side + rs.randint(-2 * spread - 1, 2 * spread + 2, (2, 600)) # wraps onto the origin
+    uv[:2, 1800:2600] = rs.randint(0, side, (2, 800))                                  # inside
+    uv[:2] += rs.uniform(0, 0.99, (2, n)) * np.sign(uv[:2])                            # astype(int) truncates
+    uv2 = uv + rs.uniform(-9, 9, (3, n))
+    truth = rs.rand(n) > 0.2
+    got = pea.disparity.flow_splat(uv, uv2, truth, side=side, spread=spread)
+    want = odisp.splat_flow_literal(uv[:, truth], (uv2 - uv)[:, truth], side=side, k=spread)
+    assert np.array_equal(got, want)
+    assert np.count_nonzero(want) > 0
+
+
 def test_point_depth_splat(pea, golden_disparity):
     z = golden_disparity
     assert np.array_equal(pea.io_utils.get_pt_depth_map(z["ptdepth_render"]), z["ptdepth_map"])
