@@ -164,14 +164,13 @@ def run_geometry(args, torch, dist, world, rank, dev):
         out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
         truth = torch.empty((P, n), dtype=torch.uint8, device=dev)
         packed = torch.empty((P, 540, 960), dtype=torch.int64, device=dev)
-        zdepth = torch.empty((P, 540, 960), dtype=torch.float32, device=dev)
 
         def step():
+            # project -> packed (depth | index) z-buffer -> visibility flags read from the packed keys
             _abi.check(_abi.lib.ispa_project(pts.data_ptr(), n, cams.data_ptr(), P, out.data_ptr(), st()))
-            _abi.check(_abi.lib.ispa_zbuffer(out.data_ptr(), n, P, 540, 960, 0, packed.data_ptr(), None,
-                                             zdepth.data_ptr(), st()))
-            _abi.check(_abi.lib.ispa_zbuffer_visibility(out.data_ptr(), n, P, zdepth.data_ptr(), 540, 960, 0.01,
-                                                        truth.data_ptr(), st()))
+            _abi.check(_abi.lib.ispa_zbuffer(out.data_ptr(), n, P, 540, 960, 0, packed.data_ptr(), None, None, st()))
+            _abi.check(_abi.lib.ispa_zbuffer_visibility_packed(out.data_ptr(), n, P, packed.data_ptr(), 540, 960,
+                                                               0.01, truth.data_ptr(), st()))
         units, unit_name, recs = P, "pose-maps/s", 2
         # project: points read once + 24 B out per point-pose; z-buffer update kernel: 24 B in and one
         # 8-byte atomic per point-pose (the memset and resolve launches around it are not in its time)

@@ -127,6 +127,10 @@ int ispa_zbuffer(const double *pt_render, int64_t n, int n_pose, int H, int W, i
 /* visible = takes part && (double)z - (double)depth[y][x] <= relax. */
 int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, const float *depth,
                             int H, int W, double relax, uint8_t *truth, void *stream);
+/* The same test with the depth taken from the packed keys ispa_zbuffer leaves in `packed` (no
+ * winner / depth decode needed in between). */
+int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n, int n_pose, const uint64_t *packed,
+                                   int H, int W, double relax, uint8_t *truth, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense nearest-neighbour correspondence

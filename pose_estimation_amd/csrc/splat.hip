@@ -335,8 +335,10 @@ __global__ __launch_bounds__(kThreads) void zbuffer_resolve_kernel(const unsigne
     if (depth) depth[pix] = empty ? __builtin_inff() : __uint_as_float((uint32_t)(k >> 32));
 }
 
+// PACKED: the depth comes straight from the high half of the packed z-buffer keys (no resolve pass)
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void zbuffer_visibility_kernel(const double *__restrict__ pt_render,
-                                                                      int64_t n, const float *__restrict__ depth,
+                                                                      int64_t n, const void *__restrict__ image,
                                                                       int H, int W, double relax,
                                                                       uint8_t *__restrict__ truth) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -345,7 +347,19 @@ __global__ __launch_bounds__(kThreads) void zbuffer_visibility_kernel(const doub
     int x, y;
     double z;
     bool vis = zbuf_pixel(pt_render + (int64_t)p * 3 * n, n, i, H, W, x, y, z);
-    if (vis) vis = (z - (double)depth[((int64_t)p * H + y) * W + x]) <= relax;
+    if (vis) {
+        const int64_t pix = ((int64_t)p * H + y) * W + x;
+        float d;
+        if (PACKED) {
+            // the 4 high bytes of the little-endian key; an empty pixel (all ones) counts as +inf, as
+            // in the resolved depth image
+            const uint32_t hi = reinterpret_cast<const uint32_t *>(image)[2 * pix + 1];
+            d = hi == 0xffffffffu ? __builtin_inff() : __uint_as_float(hi);
+        } else {
+            d = reinterpret_cast<const float *>(image)[pix];
+        }
+        vis = (z - (double)d) <= relax;
+    }
     truth[(int64_t)p * n + i] = vis;
 }
 
@@ -445,8 +459,20 @@ extern "C" int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n
     ISPA_REQUIRE(pt_render && depth && truth, "null pointer");
     ISPA_REQUIRE(H > 0 && W > 0, "bad shape");
     ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
-    hipLaunchKernelGGL(zbuffer_visibility_kernel, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads),
+    hipLaunchKernelGGL(zbuffer_visibility_kernel<false>, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads),
                        0, (hipStream_t)stream, pt_render, n, depth, H, W, relax, truth);
+    return ispa::check_launch("zbuffer_visibility_kernel");
+}
+
+extern "C" int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n, int n_pose, const uint64_t *packed,
+                                              int H, int W, double relax, uint8_t *truth, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_pose >= 0, "negative size");
+    if (n == 0 || n_pose == 0) return ISPA_OK;
+    ISPA_REQUIRE(pt_render && packed && truth, "null pointer");
+    ISPA_REQUIRE(H > 0 && W > 0, "bad shape");
+    ISPA_REQUIRE(n_pose <= 65535, "too many poses per call (%d)", n_pose);
+    hipLaunchKernelGGL(zbuffer_visibility_kernel<true>, dim3(ispa::blocks_for(n, kThreads), n_pose), dim3(kThreads),
+                       0, (hipStream_t)stream, pt_render, n, packed, H, W, relax, truth);
     return ispa::check_launch("zbuffer_visibility_kernel");
 }
 

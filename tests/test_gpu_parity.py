@@ -305,6 +305,8 @@ def test_zbuffer(pea, golden_geometry):
         assert np.array_equal(got["packed"].view(np.uint64), key)
         vis = pea.zbuffer.visibility(r, got["depth"], relax=0.01)
         assert np.array_equal(vis, ozb.zbuffer_visibility(r, depth, relax=0.01))
+        # straight from the packed keys, without the decoded depth image
+        assert np.array_equal(pea.zbuffer.visibility(r, got["packed"], relax=0.01), vis)
     # many poses: more than 2^20 blocks in the resolve launch
     import torch
     big = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(r, (600,) + r.shape))).cuda()
