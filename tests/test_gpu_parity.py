@@ -179,6 +179,22 @@ def test_get_pt_and_grid_indices(pea, golden_disparity, golden_geometry):
     assert np.array_equal(pea.correspondence.knn_inds_to_grid(got[0, :, :2]), okp.knn_inds_to_grid(want[0, :, :2]))
 
 
+def test_spatial_order_is_a_pure_permutation(pea):
+    rs = np.random.RandomState(3)
+    pts = rs.uniform(-0.4, 0.4, (20000, 3))
+    perm = pea.run_proj.spatial_order(pts)
+    assert sorted(perm.tolist()) == list(range(20000))
+    cams = pea.pt2render.camera_matrices(np.array([[30.0, 10.0, 0.0, 3.0], [200.0, -5.0, 3.0, 2.5]]))
+    depth = np.full((540, 960), 3.0, np.float32)
+    t0, r0 = pea.run_proj.project_prune(pts, cams, depth, [100, 400, 300, 700])
+    t1, r1 = pea.run_proj.project_prune(pts[perm], cams, depth, [100, 400, 300, 700])
+    assert np.array_equal(t1, t0[:, perm]) and np.array_equal(r1, r0[:, :, perm])
+    # neighbours in the array are neighbours on screen: mean pixel step shrinks by a large factor
+    step = lambda r: np.abs(np.diff(r[0, 0])).mean()
+    assert step(r1) < 0.2 * step(r0)
+    assert len(pea.run_proj.spatial_order(np.zeros((0, 3)))) == 0
+
+
 # ---------------------------------------------------------------- splat writers
 @pytest.mark.parametrize("tag", ["cloud", "mesh", "edge"])
 def test_make_disparity_golden(pea, golden_disparity, tag):
