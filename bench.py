@@ -146,20 +146,21 @@ def run_geometry(args, torch, dist, world, rank, dev):
         def unit(*shape):
             x = torch.randn(*shape, device=dev, generator=g)
             return (x / x.norm(dim=1, keepdim=True)).contiguous()
-        f_real = unit(bsz, 128, 56, 56)
-        f_tmpl = [unit(bsz, 128, 56, 56) for _ in range(views)]
-        knn = [torch.randint(0, 28, (kpts, 2), device=dev, generator=g) for _ in range(views)]
+        # eccv_net.Net.forward's inputs: real and template features per view, one keypoint list per view
+        f_i = torch.stack([unit(bsz, 128, 56, 56) for _ in range(views)], dim=1).contiguous()
+        f_j = torch.stack([unit(bsz, 128, 56, 56) for _ in range(views)], dim=1).contiguous()
+        knn = np.random.RandomState(7 + rank).randint(0, 28, (views, kpts, 2))     # host list, as in the reference
         mask = (torch.rand(bsz, 1, 56, 56, device=dev, generator=g) > 0.3).float()
         layer = co.CorrelationMapLayer()
+        f_real, f_tmpl0 = f_i[:, 0].contiguous(), f_j[:, 0].contiguous()
 
         def step():
-            for v in range(views):                      # eccv_net.Net.forward: one keypoint map set per view
-                layer.forward(f_real, f_tmpl[v], knn[v])
-            co.correlation_map_acmm(f_real, f_tmpl[0], mask)     # net_final_old: one dense map per pair
-        units, unit_name, recs = bsz, "pairs/s", views + 1
+            layer.forward_views(f_i, f_j, knn)                   # eccv_net.py:282-289, all views in one call
+            co.correlation_map_acmm(f_real, f_tmpl0, mask)       # net_final_old: one dense map per pair
+        units, unit_name, recs = bsz, "pairs/s", 2
         cells = 28 * 28
-        alg_bytes = [4.0 * bsz * 128 * cells + 4.0 * bsz * kpts * cells] * views + [2.0 * cells * cells * 128 * bsz]
-        names = ["corr_eccv"] * views + ["corr_acmm_gemm"]
+        alg_bytes = [(4.0 * bsz * 128 * cells + 4.0 * bsz * kpts * cells) * views, 2.0 * cells * cells * 128 * bsz]
+        names = ["corr_eccv", "corr_acmm_gemm"]
         workload = (f"correlation maps at the reference's size: {views} x eccv keypoint maps (K={kpts}) + 1 x acmm "
                     f"dense map for {bsz} pairs of 128x56x56 features per GPU per step")
     elif args.workload == "zbuffer":

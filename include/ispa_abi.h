@@ -189,6 +189,13 @@ int ispa_resize_bilinear(const float *in, int B, int C, int H, int W, int oh, in
 int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
                        int W, int K, int grid, float *out, float *workspace, void *stream);
 
+/* The per-view loop of eccv_net.Net.forward around that layer, in one call
+ *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:282-289 (loop, stack, permute)
+ * f1, f2 (B,V,C,H,W) f32; knn (V,K,2) int64, one keypoint list per view; out (B,V,K,grid,grid) f32,
+ * which is the reference's `embedding` before its .view().  workspace: 2*B*V*C*grid*grid floats. */
+int ispa_corr_map_eccv_views(const float *f1, const float *f2, const int64_t *knn, int B, int V, int C, int H,
+                             int W, int K, int grid, float *out, float *workspace, void *stream);
+
 /* acmm_net CorrelationMapLayer.forward, correlation part
  *   classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
  * mask (B,1,H,W) f32 (max-pooled 2x2 ceil inside).  out (B, grid*grid, grid, grid) f32.

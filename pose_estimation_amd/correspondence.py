@@ -159,9 +159,7 @@ class CorrelationMapLayer:
         f2 = dv.to_dev(feature2, torch.float32)
         if f1.shape != f2.shape or f1.dim() != 4:
             raise ValueError("feature maps must be two (B,C,H,W) arrays of the same shape")
-        knn = dv.to_dev(knn_inds, torch.int64).reshape(-1, 2)
-        if knn.numel() and (int(knn.min()) < 0 or int(knn.max()) >= self.grid):
-            raise IndexError(f"knn_inds outside the {self.grid} x {self.grid} grid")
+        knn = self._knn(knn_inds).reshape(-1, 2)
         b, c, h, w = f1.shape
         k = knn.shape[0]
         out = dv.empty((b, k, self.grid, self.grid), torch.float32)
@@ -171,6 +169,34 @@ class CorrelationMapLayer:
         return dv.back(out, as_tensor)
 
     __call__ = forward
+
+    def _knn(self, knn_inds):
+        # host lists / arrays (what the reference passes, eccv_net.py:279) are range-checked without
+        # touching the device; a device tensor costs one synchronising read
+        host = knn_inds.cpu().numpy() if dv.is_tensor(knn_inds) else np.asarray(knn_inds)
+        if host.size and (host.min() < 0 or host.max() >= self.grid):
+            raise IndexError(f"knn_inds outside the {self.grid} x {self.grid} grid")
+        return dv.to_dev(knn_inds, torch.int64)
+
+    def forward_views(self, feature_i, feature_j, knn_inds):
+        """The per-view loop of eccv_net.Net.forward (eccv_net.py:282-289) in one call:
+        feature_i, feature_j (B,V,C,H,W), knn_inds (V,K,2) -> (B,V,K,grid,grid), the reference's
+        `embedding` after stack + permute."""
+        as_tensor = dv.is_tensor(feature_i)
+        f1 = dv.to_dev(feature_i, torch.float32)
+        f2 = dv.to_dev(feature_j, torch.float32)
+        if f1.shape != f2.shape or f1.dim() != 5:
+            raise ValueError("feature maps must be two (B,V,C,H,W) arrays of the same shape")
+        knn = self._knn(knn_inds)
+        b, v, c, h, w = f1.shape
+        if knn.dim() != 3 or knn.shape[0] != v or knn.shape[2] != 2:
+            raise ValueError("knn_inds must be (V,K,2)")
+        k = knn.shape[1]
+        out = dv.empty((b, v, k, self.grid, self.grid), torch.float32)
+        ws = _workspace(2 * b * v * c * self.grid * self.grid * 4)
+        _abi.check(_abi.lib.ispa_corr_map_eccv_views(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, v, c, h, w, k, self.grid,
+                                                     dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
+        return dv.back(out, as_tensor)
 
 
 def correlation_map_acmm(feature1, feature2, mask, grid=28):

@@ -42,15 +42,17 @@ __device__ __forceinline__ float block_sum(float v, float *scratch) {
 }
 
 // one block per (b, k): out[b][k][:] = relu(t . f1[:, p]) / sum_p exp(...) * 10
+// (item b of a (B, views, ...) batch uses the keypoint list of view b % views)
 __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict__ f1r, const float *__restrict__ f2r,
-                                                        const int64_t *__restrict__ knn, int C, int grid, int K,
-                                                        float *__restrict__ out) {
+                                                        const int64_t *__restrict__ knn, int views, int C, int grid,
+                                                        int K, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tmpl = sm;            // C floats
     float *scratch = sm + C;     // 4 floats
     const int k = blockIdx.x, b = blockIdx.y;
     const int cells = grid * grid;
-    const int kx = (int)knn[2 * k], ky = (int)knn[2 * k + 1];
+    const int64_t *kn = knn + (int64_t)(b % views) * K * 2;
+    const int kx = (int)kn[2 * k], ky = (int)kn[2 * k + 1];
     const int64_t base = (int64_t)b * C * cells;
     for (int c = threadIdx.x; c < C; c += 256) tmpl[c] = f2r[base + (int64_t)c * cells + ky * grid + kx];
     __syncthreads();
@@ -259,22 +261,28 @@ extern "C" int ispa_resize_bilinear(const float *in, int B, int C, int H, int W,
     return launch_resize(in, (int64_t)B * C, H, W, oh, ow, out, (hipStream_t)stream);
 }
 
-extern "C" int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
-                                  int W, int K, int grid, float *out, float *workspace, void *stream) {
-    ISPA_REQUIRE(B >= 0 && K >= 0 && C > 0 && H > 0 && W > 0 && grid > 0, "bad shape");
+extern "C" int ispa_corr_map_eccv_views(const float *f1, const float *f2, const int64_t *knn, int B, int V, int C,
+                                        int H, int W, int K, int grid, float *out, float *workspace, void *stream) {
+    ISPA_REQUIRE(B >= 0 && V >= 1 && K >= 0 && C > 0 && H > 0 && W > 0 && grid > 0, "bad shape");
     ISPA_REQUIRE(grid <= 4096, "grid %d too large", grid);
-    ISPA_REQUIRE(C <= 8192 && B <= 65535, "C or B too large");
+    ISPA_REQUIRE(C <= 8192 && (int64_t)B * V <= 65535, "C or B x V too large");
     if (B == 0 || K == 0) return ISPA_OK;
     ISPA_REQUIRE(f1 && f2 && knn && out && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    float *f1r = workspace, *f2r = workspace + (int64_t)B * C * grid * grid;
-    if (int rc = launch_resize(f1, (int64_t)B * C, H, W, grid, grid, f1r, s)) return rc;
-    if (int rc = launch_resize(f2, (int64_t)B * C, H, W, grid, grid, f2r, s)) return rc;
+    const int items = B * V;
+    float *f1r = workspace, *f2r = workspace + (int64_t)items * C * grid * grid;
+    if (int rc = launch_resize(f1, (int64_t)items * C, H, W, grid, grid, f1r, s)) return rc;
+    if (int rc = launch_resize(f2, (int64_t)items * C, H, W, grid, grid, f2r, s)) return rc;
     const ispa::TimingSlot timed = ispa::timing_begin(s);
-    hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, B), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, C, grid,
-                       K, out);
+    hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, items), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, V, C,
+                       grid, K, out);
     ispa::timing_end(timed, s);
     return ispa::check_launch("corr_eccv_kernel");
+}
+
+extern "C" int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
+                                  int W, int K, int grid, float *out, float *workspace, void *stream) {
+    return ispa_corr_map_eccv_views(f1, f2, knn, B, 1, C, H, W, K, grid, out, workspace, stream);
 }
 
 extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,

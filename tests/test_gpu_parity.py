@@ -761,6 +761,20 @@ def test_pck_counts_match_numpy(pea):
 
 
 # ---------------------------------------------------------------- correlation maps
+def test_corr_eccv_views_equals_the_per_view_loop(pea):
+    rs = np.random.RandomState(61)
+    fi = rs.randn(2, 3, 64, 56, 56).astype(np.float32)
+    fj = rs.randn(2, 3, 64, 56, 56).astype(np.float32)
+    knn = rs.randint(0, 28, (3, 10, 2))
+    layer = pea.correspondence.CorrelationMapLayer()
+    got = layer.forward_views(fi, fj, knn)
+    assert got.shape == (2, 3, 10, 28, 28)
+    for v in range(3):                                   # eccv_net.py:282-289: loop, stack, permute
+        assert np.array_equal(got[:, v], layer.forward(fi[:, v], fj[:, v], knn[v]))
+    with pytest.raises(IndexError):
+        layer.forward_views(fi, fj, knn + 20)
+
+
 @pytest.mark.parametrize("tag", ["b1k1", "b2k10", "b3k14"])
 def test_corr_eccv_golden(pea, golden_correlation, tag):
     z = golden_correlation
