@@ -3,15 +3,24 @@
 // Contract: the `KNN` layer of the Caffe-UCN fork as the reference uses it
 // (ucn_code/nets/train.prototxt:2116-2141; consumer hard_negative_processing_layer.py:175-192).
 //
-// Structure (one call = 4 launches on the caller's stream):
-//   1. norms      nh[j] = -0.5 * |x_j|^2 for queries and references, max reference norm per pair
+// Structure (one call = 5 or 6 launches on the caller's stream):
+//   1. norms      nh[j] = -0.5 * |x_j|^2 for queries and references (float64 sums kept for step 4),
+//                 max reference norm per pair; the split variant also writes the bf16 hi / lo images
 //   2. filter     MFMA contraction  s[j][i] = r_j . q_i - 0.5 |r_j|^2  (the accumulator starts at
 //                 nh[j]), reduced in registers to the (k+1) largest s per query and partial
-//                 stream; the Nq x Nr score matrix never leaves the register file
+//                 stream; the Nq x Nr score matrix never leaves the register file.  Variants:
+//                 2a  float32 MFMA, tiles staged in LDS (any k, any C, converting loader for odd shapes)
+//                 2a' float32 MFMA, query fragments resident in registers (top-1, C <= 128)
+//                 2b  bfloat16 32x32x16 MFMA (k > 1, C <= 256)
+//                 2c  bfloat16 16x16x32 MFMA, tagged top-1 (C <= 256)
+//                 2d  float32 inputs as a bfloat16 hi/lo split on the 16x16x32 MFMA (top-1, C <= 128)
 //   3. finalize   merges the partial streams; a query whose consecutive score gaps all exceed
-//                 the rounding bound of the filter is final, the others are queued
+//                 the rounding bound of the filter is final; inside the bound the references that
+//                 can still matter are re-scored in float64 when they are all known by index,
+//                 otherwise the query is queued
 //   4. exact      float64 re-scoring of every reference for the queued queries, in the channel
 //                 order the CPU oracle uses, so the index order is exact under all inputs
+//                 (a batched top-1 variant shares one sweep over a pair's reference map)
 #include <type_traits>
 
 #include "common.h"
