@@ -134,12 +134,24 @@ __global__ __launch_bounds__(kThreads) void project_prune2_kernel(
     int poses_per_block, const float *__restrict__ depth, int depth_per_pose, int H, int W, int ylim,
     int xlim, double relax, const int32_t *__restrict__ crop, int crop_per_pose,
     double *__restrict__ out, uint8_t *__restrict__ truth, uint8_t *__restrict__ truth_depth,
-    uint8_t *__restrict__ truth_crop) {
-    const int64_t i2 = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (2 * i2 >= n) return;
+    uint8_t *__restrict__ truth_crop, int nb_x) {
+    // 1-D grid; blocks b and b + 8 run on the same XCD.  With one depth map per pose, all point
+    // blocks of one pose group are given to one XCD, so that the depth texels gathered for those poses
+    // stay in a single L2 (measured -15..-20 %); with a shared depth map the plain order is kept.
+    int group, xb;
+    if (depth_per_pose) {
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        group = (w / nb_x) * 8 + xcd;
+        xb = w % nb_x;
+    } else {
+        group = blockIdx.x / nb_x;
+        xb = blockIdx.x % nb_x;
+    }
+    const int64_t i2 = (int64_t)xb * kThreads + threadIdx.x;
+    const int p0 = group * poses_per_block;
+    if (2 * i2 >= n || p0 >= n_pose) return;
     const double2 *src = reinterpret_cast<const double2 *>(pts + 6 * i2);
     const double2 l0 = src[0], l1 = src[1], l2 = src[2];
-    const int p0 = blockIdx.y * poses_per_block;
     const int p1 = min(p0 + poses_per_block, n_pose);
     // crop, remap and store one pose's pair of points
     auto finish = [&](int p, double2 u, double2 v, double2 z, bool vis0, bool vis1) {
@@ -275,13 +287,20 @@ extern "C" int ispa_project_prune(const double *pts, int64_t n, const double *ca
     const int ppb = pick_poses_per_block(work, n_pose);
     dim3 grid(ispa::blocks_for(work, kThreads), (n_pose + ppb - 1) / ppb);
     ISPA_REQUIRE(grid.y <= 65535, "too many poses per call (%d)", n_pose);
-    auto kernel = variant == ISPA_VIS_A
-                      ? (vec2 ? project_prune2_kernel<ISPA_VIS_A> : project_prune_kernel<ISPA_VIS_A>)
-                      : (vec2 ? project_prune2_kernel<ISPA_VIS_B> : project_prune_kernel<ISPA_VIS_B>);
     const ispa::TimingSlot timed = ispa::timing_begin((hipStream_t)stream);
-    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose, ppb, depth,
-                       depth_per_pose, H, W, ylim, xlim, relax, crop, crop_per_pose, out, truth, truth_depth,
-                       truth_crop);
+    if (vec2) {
+        const int64_t nblocks = (int64_t)grid.x * (depth_per_pose ? 8 * ((grid.y + 7) / 8) : grid.y);
+        ISPA_REQUIRE(nblocks < (1ll << 31), "problem too large for one launch");
+        hipLaunchKernelGGL(variant == ISPA_VIS_A ? project_prune2_kernel<ISPA_VIS_A> : project_prune2_kernel<ISPA_VIS_B>,
+                           dim3((unsigned)nblocks), dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose, ppb,
+                           depth, depth_per_pose, H, W, ylim, xlim, relax, crop, crop_per_pose, out, truth,
+                           truth_depth, truth_crop, (int)grid.x);
+    } else {
+        hipLaunchKernelGGL(variant == ISPA_VIS_A ? project_prune_kernel<ISPA_VIS_A> : project_prune_kernel<ISPA_VIS_B>,
+                           grid, dim3(kThreads), 0, (hipStream_t)stream, pts, n, cams, n_pose, ppb, depth,
+                           depth_per_pose, H, W, ylim, xlim, relax, crop, crop_per_pose, out, truth, truth_depth,
+                           truth_crop);
+    }
     ispa::timing_end(timed, (hipStream_t)stream);
     return ispa::check_launch("project_prune_kernel");
 }
