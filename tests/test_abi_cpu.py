@@ -66,3 +66,18 @@ def test_host_helpers_without_gpu():
     assert np.array_equal(correspondence.knn_inds_to_grid(xy), okp.knn_inds_to_grid(xy))
     ind = rs.randint(1, 3137, (2, 1, 50))
     assert np.array_equal(correspondence.ind2coord(ind, 56), okp.ind2coord(ind, 56))
+
+
+def test_spatial_order_host_logic():
+    import numpy as np
+    from pose_estimation_amd import run_proj
+    rs = np.random.RandomState(5)
+    pts = rs.uniform(-1, 1, (5000, 3))
+    perm = run_proj.spatial_order(pts)
+    assert perm.dtype == np.int64 and sorted(perm.tolist()) == list(range(5000))
+    step = lambda p: np.linalg.norm(np.diff(p, axis=0), axis=1).mean()
+    assert step(pts[perm]) < 0.25 * step(pts)                # neighbours in the array are neighbours in space
+    assert np.array_equal(run_proj.spatial_order(pts), perm)  # deterministic
+    flat = pts.copy()
+    flat[:, 2] = 0.5                                          # a degenerate axis must not divide by zero
+    assert sorted(run_proj.spatial_order(flat).tolist()) == list(range(5000))
