@@ -285,7 +285,8 @@ def test_flow_splat_slice_semantics(pea):
     assert empty.shape == (224, 224, 2) and not empty.any()
 
 
-@pytest.mark.parametrize("spread,side", [(1, 224), (2, 224), (3, 224), (4, 224), (5, 224), (2, 64), (4, 9), (2, 3)])
+@pytest.mark.parametrize("spread,side", [(1, 224), (2, 224), (3, 224), (4, 224), (5, 224), (2, 64), (4, 9), (2, 3),
+                                         (2, 1000), (6, 300), (4, 3000)])
 def test_flow_splat_wild_coordinates(pea, spread, side):
     """Coordinates far outside the map, on every border and negative (Python slices wrap): the
     anchor-image path (spread <= 4) and the per-pixel atomic path must both match the literal loop."""
