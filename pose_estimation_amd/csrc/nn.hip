@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val, int *__restrict__ part_idx) {
     constexpr int C = NKS * kKC;
     __shared__ __attribute__((aligned(16))) float Rs[kRing][kKC][kTR];
-    __shared__ float Nh[2][kTR];
+    __shared__ __attribute__((aligned(16))) float Nh[2][kTR];
 
     int bid = xcd_order(blockIdx.x, gridDim.x);
     const int qt = bid % n_qtiles;
@@ -626,13 +626,17 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     int st = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         f32x16 acc[2][2];
+        // register reg of a tile is reference row (reg & 3) + 8 (reg >> 2) + 4 h: four consecutive
+        // floats per reg >> 2, one 16-byte LDS read each
 #pragma unroll
         for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float init = Nh[chunk & 1][wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
-                acc[ri][0][reg] = init;
-                acc[ri][1][reg] = init;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 t = *reinterpret_cast<const float4 *>(&Nh[chunk & 1][wr * 64 + ri * 32 + 8 * g4 + 4 * h]);
+                acc[ri][0][4 * g4 + 0] = acc[ri][1][4 * g4 + 0] = t.x;
+                acc[ri][0][4 * g4 + 1] = acc[ri][1][4 * g4 + 1] = t.y;
+                acc[ri][0][4 * g4 + 2] = acc[ri][1][4 * g4 + 2] = t.z;
+                acc[ri][0][4 * g4 + 3] = acc[ri][1][4 * g4 + 3] = t.w;
             }
         unsigned voff[(NKS + kRing - 2) / NKS + 1];
 #pragma unroll
