@@ -1316,7 +1316,7 @@ constexpr int split_filter_lds_bytes() {
 }
 
 template <int KS32>
-__global__ __launch_bounds__(256, 2) void nn_filter_split_kernel(
+__global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
     const uint16_t *__restrict__ qhi, const uint16_t *__restrict__ qlo, const uint16_t *__restrict__ rhi,
     const uint16_t *__restrict__ rlo, const float *__restrict__ rnh, int64_t nq, int64_t nr, int n_qtiles,
     int nsplit, int64_t refs_per_split, float *__restrict__ part_val, int *__restrict__ part_idx) {
@@ -2055,7 +2055,7 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
     const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0 && nr < (1 << 27);   // 32-bit lane offsets
     p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && C <= 256;
-    p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 128 && k == 1;
+    p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 256 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
     const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
     p.t16 = p.bf16_mfma && k == 1;          // top-1: the 16x16x32 kernel
@@ -2213,7 +2213,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
             case 1: rc = launch_split<1>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
             case 2: rc = launch_split<2>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
             case 3: rc = launch_split<3>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
-            default: rc = launch_split<4>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 4: rc = launch_split<4>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 5: rc = launch_split<5>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 6: rc = launch_split<6>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            case 7: rc = launch_split<7>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
+            default: rc = launch_split<8>(grid, s, qhi, qlo, rhi, rlo, rnh, nq, nr, p, pval, pidx); break;
         }
         if (rc) return rc;
     } else if (p.bf16_mfma) {

@@ -589,10 +589,13 @@ def test_nn_split_filter(pea):
     rs = np.random.RandomState(41)
     for (b, c, nq, nr) in ((2, 128, 1024, 2048), (1, 64, 264, 520), (3, 32, 8, 136), (1, 96, 520, 1032)):
         _nn_check(pea, _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr)), 1, split=True)
-    # requests the split kernel does not take run as plain float32 (k > 1, odd sizes, C = 256)
+    # 160 .. 256 channels: one block per CU
+    for c in (160, 192, 224, 256):
+        _nn_check(pea, _unit(rs, (1, c, 264)), _unit(rs, (1, c, 1032)), 1, split=True)
+    # requests the split kernel does not take run as plain float32 (k > 1, odd sizes, C = 288)
     _nn_check(pea, _unit(rs, (1, 128, 256)), _unit(rs, (1, 128, 512)), 5, split=True)
     _nn_check(pea, _unit(rs, (2, 48, 100)), _unit(rs, (2, 48, 333)), 1, split=True)
-    _nn_check(pea, _unit(rs, (1, 256, 512)), _unit(rs, (1, 256, 1024)), 1, split=True)
+    _nn_check(pea, _unit(rs, (1, 288, 512)), _unit(rs, (1, 288, 1024)), 1, split=True)
     # unnormalised features with a wide dynamic range, duplicates and near-duplicates
     q = (rs.randn(2, 128, 512) * rs.uniform(0.01, 30.0, (1, 128, 1))).astype(np.float32)
     r = (rs.randn(2, 128, 1024) * rs.uniform(0.01, 30.0, (1, 128, 1))).astype(np.float32)
