@@ -27,7 +27,7 @@ def _workspace(nbytes):
     return ws
 
 
-def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native"):
+def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native", num_query=None):
     """k nearest reference cells (squared L2) for every query column.
 
     query (B,C,Hq,Wq) or (B,C,n); ref (B,C,H,W) or (B,C,nr); float32, or bfloat16 torch tensors.
@@ -36,7 +36,11 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native")
     exact with respect to float64 arithmetic on the given inputs.
 
     filter="split" (float32 inputs, k=1): the filter pass contracts a bfloat16 hi/lo split of the
-    inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones."""
+    inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones.
+
+    num_query (B,) or (B,1): the layer's `num_coord` bottom with `use_all_query: false`
+    (train.prototxt:2128-2141) - only the first num_query[b] query columns of item b are real; the
+    others come back as index -1 and distance +inf."""
     if filter not in ("native", "split"):
         raise ValueError("filter must be 'native' or 'split'")
     as_tensor = dv.is_tensor(query)
@@ -64,6 +68,14 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native")
     _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), code, b, c, nq, nr, k,
                                      int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
                                      dv.ptr(stats), dv.stream_ptr()))
+    if num_query is not None:
+        nv = dv.to_dev(np.asarray(num_query).reshape(-1) if not dv.is_tensor(num_query) else num_query.reshape(-1),
+                       torch.int64)
+        if nv.numel() != b:
+            raise ValueError("num_query must hold one count per batch item")
+        pad = torch.arange(nq, device=nv.device)[None, None, :] >= nv[:, None, None]
+        ind.masked_fill_(pad, -1)
+        dist.masked_fill_(pad, float("inf"))
     out = (dv.back(dist, as_tensor), dv.back(ind, as_tensor))
     if return_stats:
         st = stats.cpu().tolist()

@@ -732,6 +732,11 @@ def test_extract_feature_then_knn(pea):
     _nn_check(pea, qf, f2.reshape(3, 128, -1), 1)
     with pytest.raises(ValueError):
         pea.correspondence.extract_feature(f1, corr[:, :, :1])
+    # num_coord bottom of the KNN layer (use_all_query: false): padded query slots are marked
+    d_all, i_all = pea.correspondence.dense_nn(qf, f2, 1)
+    d_n, i_n = pea.correspondence.dense_nn(qf, f2, 1, num_query=np.array([[300], [17], [0]]))
+    assert np.array_equal(i_n[0], i_all[0]) and np.array_equal(i_n[1, :, :17], i_all[1, :, :17])
+    assert (i_n[1, :, 17:] == -1).all() and np.isinf(d_n[1, :, 17:]).all() and (i_n[2] == -1).all()
 
 
 def test_pck_counts_match_numpy(pea):
