@@ -2,9 +2,9 @@
 
     python tools/profile_collect.py gpurun_out profiles r01
 
-Per workload tag: <round>_stats_<tag>_kernel_stats.csv (rocprofv3 --stats), <round>_stats_<tag>_bench.json (the bench
-line of that same profiled run), <round>_pmc_<tag>_<COUNTERS>.csv (mean counter value per kernel),
-<round>_pmc_traffic.json (tools/pmc_summary.py) and <round>_bench_default.json.
+Per workload tag: <prefix>_stats_<tag>_kernel_stats.csv (rocprofv3 --stats), <prefix>_stats_<tag>_bench.json (the bench
+line of that same profiled run), <prefix>_pmc_<tag>_<COUNTERS>.csv (mean counter value per kernel),
+<prefix>_pmc_traffic.json (tools/pmc_summary.py) and <prefix>_bench_default.json.
 """
 import collections
 import csv
