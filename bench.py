@@ -99,12 +99,14 @@ def measured_traffic(workload_key, kernel, is_default_shape):
     if not is_default_shape:
         return None
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[workload_key]
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        table = json.load(open(newest))[workload_key]
         if kernel in table:
             return table[kernel]["traffic_bytes"]
         hits = [v["traffic_bytes"] for k, v in table.items() if k.startswith(kernel.replace("_kernel", ""))]
         return hits[0] if len(hits) == 1 else None
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 
