@@ -1560,7 +1560,8 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                                                           int *__restrict__ amb_list,
                                                           int *__restrict__ pair_count,
                                                           int *__restrict__ pair_list,
-                                                          int *__restrict__ light_count) {
+                                                          int *__restrict__ light_count,
+                                                          int *__restrict__ light_list) {
     const int b = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
@@ -1574,30 +1575,49 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         v[s] = kNegInf;
         c[s] = -1;
     }
-    for (int p = 0; p < nparts; ++p)
-        for (int s = 0; s <= K; ++s) {
-            const int64_t o = (((int64_t)b * nparts + p) * (K + 1) + s) * nq + i;
-            const float x = part_val[o];
-            const unsigned code = (unsigned)part_idx[o];   // -1 sorts after every real index
-            if (!(x > kAbsent) && x == x) break;            // absent (NaN falls through)
-            if (x > v[K] || (x == v[K] && code < (unsigned)c[K]) || x != x) {
-                v[K] = x;
-                c[K] = (int)code;
+    // the lists of several streams are loaded together (a thread that waited for each entry before
+    // asking for the next would spend ~1 us per entry: with many streams that is the kernel's duration)
+    constexpr int PB = K == 1 ? 8 : (K <= 5 ? 2 : 1);
+    for (int p0 = 0; p0 < nparts; p0 += PB) {
+        float xs[PB][K + 1];
+        int cs[PB][K + 1];
 #pragma unroll
-                for (int t = K; t > 0; --t) {
-                    const bool sw = v[t] > v[t - 1] || (v[t] == v[t - 1] && (unsigned)c[t] < (unsigned)c[t - 1]) ||
-                                    v[t] != v[t];
-                    if (sw) {
-                        const float tv = v[t];
-                        v[t] = v[t - 1];
-                        v[t - 1] = tv;
-                        const int tc = c[t];
-                        c[t] = c[t - 1];
-                        c[t - 1] = tc;
+        for (int e = 0; e < PB; ++e)
+#pragma unroll
+            for (int s = 0; s <= K; ++s) {
+                const int pp = p0 + e < nparts ? p0 + e : nparts - 1;
+                const int64_t o = (((int64_t)b * nparts + pp) * (K + 1) + s) * nq + i;
+                xs[e][s] = part_val[o];
+                cs[e][s] = part_idx[o];
+            }
+#pragma unroll
+        for (int e = 0; e < PB; ++e) {
+            if (p0 + e >= nparts) break;
+#pragma unroll
+            for (int s = 0; s <= K; ++s) {
+                const float x = xs[e][s];
+                const unsigned code = (unsigned)cs[e][s];   // -1 sorts after every real index
+                if (!(x > kAbsent) && x == x) break;        // absent (NaN falls through)
+                if (x > v[K] || (x == v[K] && code < (unsigned)c[K]) || x != x) {
+                    v[K] = x;
+                    c[K] = (int)code;
+#pragma unroll
+                    for (int t = K; t > 0; --t) {
+                        const bool sw = v[t] > v[t - 1] ||
+                                        (v[t] == v[t - 1] && (unsigned)c[t] < (unsigned)c[t - 1]) || v[t] != v[t];
+                        if (sw) {
+                            const float tv = v[t];
+                            v[t] = v[t - 1];
+                            v[t - 1] = tv;
+                            const int tc = c[t];
+                            c[t] = c[t - 1];
+                            c[t - 1] = tc;
+                        }
                     }
                 }
             }
         }
+    }
     // two filter scores are ordered for certain when they differ by more than
     // err_rel * (|q| max|r| + max|r|^2 / 2); err_rel comes from the filter kernel's rounding model
     const float qq = -2.f * qnh[(int64_t)b * nq + i];
@@ -1628,13 +1648,14 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
     if (K == 1 && v[0] > kAbsent) {
         // Top-1, margin too small.  Every reference that can still be the exact nearest one scores
         // at least v[0] - delta.  If in every stream only the stream's best can do that, the
-        // contenders are known by index: re-score just those in float64 (the oracle's channel
-        // order) and keep the smallest (distance, index).  A stream whose runner-up is also in
-        // range may hide contenders, and then the query goes to the full float64 pass.
+        // contenders are known by index and re-scoring just those in float64 settles the query.  A
+        // stream whose runner-up is also in range may hide contenders, and then the query goes to
+        // the full float64 pass.
         const float lim = v[0] - delta;
         int cand[8];
         int nc = 0;
         bool hidden = false;
+#pragma unroll 8
         for (int p = 0; p < nparts; ++p) {
             const int64_t o = (((int64_t)b * nparts + p) * 2) * nq + i;
             const float a_s = part_val[o], b_s = part_val[o + nq];
@@ -1646,38 +1667,11 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         }
         for (int e = 0; e < nc; ++e) hidden |= cand[e] < 0;
         if (!hidden && nc >= 1) {
-            const T *qcol = q + (int64_t)b * C * nq + i;
-            const double qq_d = qq64[(int64_t)b * nq + i];
-            double best_d = __builtin_inf();
-            int best_j = 0x7fffffff;
-            for (int e = 0; e < nc; ++e) {
-                const int j = cand[e];
-                const T *rcol = r + (int64_t)b * C * nr + j;
-                double dot = 0.0;
-                int c0 = 0;
-                for (; c0 + 8 <= C; c0 += 8) {             // 16 loads in flight, then the ordered chain
-                    float qv[8], rv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
-                        rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
-                }
-                for (; c0 < C; ++c0)
-                    dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
-                              (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
-                const double d = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
-                if (d < best_d || (d == best_d && j < best_j)) {
-                    best_d = d;
-                    best_j = j;
-                }
-            }
-            const int64_t o = (int64_t)b * nq + i;       // k_out == 1
-            idx[o] = best_j + index_base;
-            dist[o] = (float)best_d;
-            if (light_count) atomicAdd(light_count, 1);
+            // known contenders: nn_rescore_top1_kernel settles the query, one wave per query (doing it
+            // here would make this one thread's dependent loads the duration of the whole kernel)
+            const int slot = atomicAdd(light_count, 1);
+            light_list[2 * slot] = (int)((int64_t)b * nq + i);
+            light_list[2 * slot + 1] = __float_as_int(lim);
             return;
         }
     }
@@ -1767,6 +1761,78 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
     amb_list[slot] = (int)((int64_t)b * nq + i);   // b*nq+i < 2^31 is checked on the host
     const int pslot = atomicAdd(&pair_count[b], 1);
     pair_list[(int64_t)b * nq + pslot] = (int)i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3b. top-1 queries whose contenders are known: one wave per query.  Lane p looks at stream p; if that
+// stream's best score reaches the query's limit, the lane re-scores that reference in float64 (the
+// oracle's channel order, 16 channels of loads in flight at a time); the wave keeps the smallest
+// (distance, index).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nn_rescore_top1_kernel(const float *__restrict__ part_val,
+                                                              const int *__restrict__ part_idx, int nparts,
+                                                              const T *__restrict__ q, const T *__restrict__ r,
+                                                              const double *__restrict__ qq64,
+                                                              const double *__restrict__ rr64, int C, int64_t nq,
+                                                              int64_t nr, int index_base,
+                                                              const int *__restrict__ light_count,
+                                                              const int *__restrict__ light_list,
+                                                              float *__restrict__ dist, int *__restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int count = *light_count;
+    for (int w = wave; w < count; w += nwaves) {
+        const int64_t flat = light_list[2 * w];
+        const float lim = __int_as_float(light_list[2 * w + 1]);
+        const int b = (int)(flat / nq);
+        const int64_t i = flat % nq;
+        const T *qcol = q + (int64_t)b * C * nq + i;
+        double best_d = __builtin_inf();
+        int best_j = 0x7fffffff;
+        for (int p0 = 0; p0 < nparts; p0 += 64) {
+            const int p = p0 + lane;
+            int j = -1;
+            if (p < nparts) {
+                const int64_t o = (((int64_t)b * nparts + p) * 2) * nq + i;
+                if (part_val[o] >= lim) j = part_idx[o];
+            }
+            if (j < 0) continue;
+            const T *rcol = r + (int64_t)b * C * nr + j;
+            double dot = 0.0;
+            int c0 = 0;
+            for (; c0 + 16 <= C; c0 += 16) {
+                float qv[16], rv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+                    rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+            }
+            for (; c0 < C; ++c0)
+                dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq), (double)load_as_float(rcol + (int64_t)c0 * nr),
+                          dot);
+            const double d = (qq64[flat] + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+            if (d < best_d || (d == best_d && j < best_j)) {
+                best_d = d;
+                best_j = j;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_xor(best_d, off);
+            const int oj = __shfl_xor(best_j, off);
+            if (od < best_d || (od == best_d && oj < best_j)) {
+                best_d = od;
+                best_j = oj;
+            }
+        }
+        if (lane == 0) {                                 // k_out == 1
+            idx[flat] = best_j + index_base;
+            dist[flat] = (float)best_d;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2046,7 +2112,7 @@ struct Plan {
     int tq;                  // queries per block of the chosen filter
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
-    size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_pcount, off_list, off_plist, off_pval, off_pidx, total;
+    size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_pcount, off_list, off_plist, off_llist, off_pval, off_pidx, total;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2088,6 +2154,7 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     p.off_pcount = take(sizeof(int) * B);
     p.off_list = take(sizeof(int) * B * nq);
     p.off_plist = take(sizeof(int) * B * nq);
+    p.off_llist = take(sizeof(int) * 2 * B * nq);
     p.off_pval = take(sizeof(float) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.off_pidx = take(sizeof(int) * (size_t)B * p.nparts * (p.ktemplate + 1) * nq);
     p.off_qhi = p.off_qlo = p.off_rhi = p.off_rlo = 0;
@@ -2168,6 +2235,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     int *list = (int *)(ws + p.off_list);
     int *pcount = (int *)(ws + p.off_pcount);
     int *plist = (int *)(ws + p.off_plist);
+    int *llist = (int *)(ws + p.off_llist);
     float *pval = (float *)(ws + p.off_pval);
     int *pidx = (int *)(ws + p.off_pidx);
 
@@ -2285,12 +2353,18 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
 #define ISPA_FINALIZE(KT)                                                                                     \
     hipLaunchKernelGGL((nn_finalize_kernel<T, KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
-                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1)
+                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1, llist)
     if (p.ktemplate == 1) ISPA_FINALIZE(1);
     else if (p.ktemplate == 5) ISPA_FINALIZE(5);
     else ISPA_FINALIZE(kMaxK);
 #undef ISPA_FINALIZE
     if (int rc = ispa::check_launch("nn_finalize_kernel")) return rc;
+    if (p.ktemplate == 1) {
+        const int64_t waves = (int64_t)B * nq < 4096 ? (int64_t)B * nq : 4096;
+        hipLaunchKernelGGL((nn_rescore_top1_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval, pidx,
+                           p.nparts, q, r, q64, r64, C, nq, nr, index_base, count + 1, llist, dist, idx);
+        if (int rc = ispa::check_launch("nn_rescore_top1_kernel")) return rc;
+    }
 
     // float64 pass: pairs with long queues (when queues are long on average) share one sweep over
     // their reference map among kQB queries; everything else goes one query per block
