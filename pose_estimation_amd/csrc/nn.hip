@@ -96,11 +96,10 @@ __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, 
 // Four consecutive cells per thread (16-byte loads for float, 8-byte for bfloat16): same sums in the
 // same channel order, wider memory transactions.  Needs n % 4 == 0 and 16-byte aligned rows.
 template <typename T>
-__global__ __launch_bounds__(256) void nn_norms4_kernel(const T *__restrict__ x, int C, int64_t n,
-                                                        float *__restrict__ nh, double *__restrict__ sq64,
-                                                        int *__restrict__ maxbits) {
-    const int b = blockIdx.y;
-    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void norms4_block(const T *__restrict__ x, int C, int64_t n, float *__restrict__ nh,
+                                             double *__restrict__ sq64, int *__restrict__ maxbits, int b,
+                                             int block) {
+    const int64_t j = ((int64_t)block * 256 + threadIdx.x) * 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (j < n) {
         const T *col = x + (int64_t)b * C * n + j;
@@ -150,6 +149,24 @@ __global__ __launch_bounds__(256) void nn_norms4_kernel(const T *__restrict__ x,
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_int(m));
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nn_norms4_kernel(const T *__restrict__ x, int C, int64_t n,
+                                                        float *__restrict__ nh, double *__restrict__ sq64,
+                                                        int *__restrict__ maxbits) {
+    norms4_block(x, C, n, nh, sq64, maxbits, blockIdx.y, blockIdx.x);
+}
+
+// query map and reference map of every pair in one launch: blocks [0, nbq) take the queries
+template <typename T>
+__global__ __launch_bounds__(256) void nn_norms4_both_kernel(const T *__restrict__ q, const T *__restrict__ r, int C,
+                                                             int64_t nq, int64_t nr, int nbq,
+                                                             float *__restrict__ qnh, double *__restrict__ q64,
+                                                             float *__restrict__ rnh, double *__restrict__ r64,
+                                                             int *__restrict__ rmax) {
+    if ((int)blockIdx.x < nbq) norms4_block(q, C, nq, qnh, q64, (int *)nullptr, blockIdx.y, blockIdx.x);
+    else norms4_block(r, C, nr, rnh, r64, rmax, blockIdx.y, blockIdx.x - nbq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2251,18 +2268,25 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
                            rlo, rnh, r64, rmax);
     } else {
         // workspace blocks are 256-byte aligned, so nh / sq64 rows are aligned whenever n % 4 == 0
-        if (nq % 4 == 0 && (uintptr_t)q % 16 == 0)
-            hipLaunchKernelGGL((nn_norms4_kernel<T>), dim3(ispa::blocks_for(nq / 4, 256), B), dim3(256), 0, s, q, C, nq,
-                               qnh, q64, (int *)nullptr);
-        else
-            hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, q, C, nq,
-                               qnh, q64, (int *)nullptr);
-        if (nr % 4 == 0 && (uintptr_t)r % 16 == 0)
-            hipLaunchKernelGGL((nn_norms4_kernel<T>), dim3(ispa::blocks_for(nr / 4, 256), B), dim3(256), 0, s, r, C, nr,
-                               rnh, r64, rmax);
-        else
-            hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr,
-                               rnh, r64, rmax);
+        const bool q4 = nq % 4 == 0 && (uintptr_t)q % 16 == 0, r4 = nr % 4 == 0 && (uintptr_t)r % 16 == 0;
+        if (q4 && r4) {
+            const unsigned nbq = ispa::blocks_for(nq / 4, 256), nbr = ispa::blocks_for(nr / 4, 256);
+            hipLaunchKernelGGL((nn_norms4_both_kernel<T>), dim3(nbq + nbr, B), dim3(256), 0, s, q, r, C, nq, nr,
+                               (int)nbq, qnh, q64, rnh, r64, rmax);
+        } else {
+            if (q4)
+                hipLaunchKernelGGL((nn_norms4_kernel<T>), dim3(ispa::blocks_for(nq / 4, 256), B), dim3(256), 0, s, q, C,
+                                   nq, qnh, q64, (int *)nullptr);
+            else
+                hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, q, C, nq,
+                                   qnh, q64, (int *)nullptr);
+            if (r4)
+                hipLaunchKernelGGL((nn_norms4_kernel<T>), dim3(ispa::blocks_for(nr / 4, 256), B), dim3(256), 0, s, r, C,
+                                   nr, rnh, r64, rmax);
+            else
+                hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr,
+                                   rnh, r64, rmax);
+        }
     }
     if (int rc = ispa::check_launch("nn_norms_kernel")) return rc;
 
