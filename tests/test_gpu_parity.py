@@ -621,6 +621,32 @@ def test_nn_split_filter(pea):
     assert torch.equal(i0, i1)
 
 
+def test_nn_pointers_off_the_16_byte_grid(pea):
+    """Feature maps that start one or a few elements into an allocation (views into a larger
+    buffer): the 16-byte loaders and LDS-direct paths must stand aside, results unchanged."""
+    import torch
+    rs = np.random.RandomState(77)
+    for (b, c, nq, nr, k) in ((2, 128, 512, 1024, 1), (1, 64, 264, 520, 5), (1, 160, 256, 512, 1)):
+        q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
+        for mode in ("f32", "bf16", "split"):
+            if mode == "split" and k != 1:
+                continue
+            tdt = torch.bfloat16 if mode == "bf16" else torch.float32
+            for off in (1, 2, 3):
+                qbuf = torch.empty(q.size + off, dtype=tdt, device="cuda")
+                rbuf = torch.empty(r.size + off, dtype=tdt, device="cuda")
+                qd, rd = qbuf[off:].view(b, c, nq), rbuf[off:].view(b, c, nr)
+                qd.copy_(torch.from_numpy(q))
+                rd.copy_(torch.from_numpy(r))
+                assert qd.data_ptr() % 16 != 0 and rd.data_ptr() % 16 != 0
+                d, i = pea.correspondence.dense_nn(qd, rd, k, 1, filter="split" if mode == "split" else "native")
+                qo = cnative.round_bf16(q) if mode == "bf16" else q
+                ro = cnative.round_bf16(r) if mode == "bf16" else r
+                for p in range(b):
+                    want_i, _ = cnative.nn_exact(qo[p], ro[p], k, 1)
+                    assert np.array_equal(i[p].cpu().numpy(), want_i), (mode, off, c)
+
+
 def test_nn_top5_c256(pea):
     rs = np.random.RandomState(12)
     _nn_check(pea, _unit(rs, (1, 256, 2048)), _unit(rs, (1, 256, 4096)), 5)
