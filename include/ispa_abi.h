@@ -232,6 +232,30 @@ int ispa_pck_counts(const int32_t *ind, int B, int k, int64_t n, const double *c
                     double downsampling, int index_base, const double *radii, int n_radii,
                     int32_t *counts, void *stream);
 
+/* Pruning of dense 2-D skeleton keypoints on annotated real images, batched over images
+ *   data_creator/utils.py:274-290 (surface_pruned), :292-325 (dir_pruned), :327-348 (surface_dir_prune);
+ *   caller data_creator/make_dense_pointset.py:91-95
+ * coords (B,2,n) f64 rows [x; y], edited IN PLACE: a pruned point becomes (0, 0), as the reference zeroes
+ * the column.  flags (B,n) u8 says which tests a point takes (OR of the ISPA_PRUNE_* bits):
+ *   POLYGON  pruned if inside or on the closed polygon (B,n_vert,2) i32 [x, y] (the seat outline; the
+ *            reference rasterises it, traces the contour and calls cv2.pointPolygonTest(...) > -1);
+ *   BAND     pruned if the pixel (trunc x, trunc y) lies within thickness/2 of one of the image's first
+ *            n_seg[b] segments (B,max_seg,4) i32 [x0, y0, x1, y1] (the reference draws them with
+ *            cv2.line(..., 255, thickness) and reads src[y, x]; a negative pixel index wraps once);
+ *   DROP     pruned unconditionally (bones surface_dir_prune removes by facing direction).
+ * pruned (optional, may be NULL) (B,n) u8 = 1 where the point was zeroed.  Corner and end point
+ * coordinates are taken clamped to [-8192, 8192]; H, W <= 8192.  The closed-form tests stand in for
+ * OpenCV's rasterisers, which are not part of the reference: points within about a pixel of an outline
+ * or band rim may be decided differently than by OpenCV. */
+#define ISPA_PRUNE_POLYGON 1
+#define ISPA_PRUNE_BAND 2
+#define ISPA_PRUNE_DROP 4
+#define ISPA_PRUNE_MAX_VERTICES 64
+#define ISPA_PRUNE_MAX_SEGMENTS 256
+int ispa_prune_points_2d(double *coords, int B, int64_t n, const uint8_t *flags, const int32_t *polygon,
+                         int n_vert, const int32_t *segments, const int32_t *n_seg, int max_seg, int thickness,
+                         int H, int W, uint8_t *pruned, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

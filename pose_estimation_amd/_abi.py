@@ -14,6 +14,8 @@ ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1
 F32, BF16, F32_SPLIT = 0, 1, 2
 PCK_MAX_RADII = 8
+PRUNE_POLYGON, PRUNE_BAND, PRUNE_DROP = 1, 2, 4
+PRUNE_MAX_VERTICES, PRUNE_MAX_SEGMENTS = 64, 256
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -48,6 +50,7 @@ SIGNATURES = {
     "ispa_extract_feature": (_i, [_p, _i, _i, _i, _i, _p, _i64, _i, _i, ctypes.c_float, _i, _p, _p]),
     "ispa_nearest_view": (_i, [_p, _i, _p, _i, _p, _p, _p]),
     "ispa_pck_counts": (_i, [_p, _i, _i, _i64, _p, _i, _d, _i, _p, _i, _p, _p]),
+    "ispa_prune_points_2d": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
 }
 
 

@@ -40,6 +40,11 @@ def test_argument_checks_do_not_need_a_gpu():
     assert _abi.lib.ispa_pck_counts(None, 0, 1, 0, None, 56, 4.0, 1, None, 0, None, None) == 0
     rc = _abi.lib.ispa_extract_feature(1, 1, 8, 4, 4, 1, 10, 5, 4, 4.0, 0, 1, None)
     assert rc == -1 and b"coordinate columns" in _abi.lib.ispa_last_error()
+    rc = _abi.lib.ispa_prune_points_2d(1, 1, 10, 1, 1, 65, None, None, 0, 5, 224, 224, None, None)
+    assert rc == -1 and b"vertices" in _abi.lib.ispa_last_error()
+    rc = _abi.lib.ispa_prune_points_2d(1, 1, 10, 1, 1, 4, None, None, 0, 5, 224, 9000, None, None)
+    assert rc == -1 and b"image size" in _abi.lib.ispa_last_error()
+    assert _abi.lib.ispa_prune_points_2d(None, 0, 0, None, None, 4, None, None, 0, 5, 224, 224, None, None) == 0
 
 
 def test_host_helpers_without_gpu():

@@ -4,7 +4,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from oracle import cnative, correlation, disparity, geometry as g, keypoints as kp, nn, zbuffer
+from oracle import cnative, correlation, disparity, geometry as g, keypoints as kp, nn, prune2d, zbuffer
 
 ANCHORS = ["bed", "chair", "sofa_b", "sofa", "table"]
 
@@ -250,3 +250,34 @@ def test_extract_feature_known_answers():
     bil = onn.extract_feature(f, coords, mode="bilinear")
     assert np.array_equal(bil[0, :, 0], [32.0, 132.0, 232.0])
     assert np.array_equal(bil[0, :, 1], [37.5, 137.5, 237.5])           # a linear ramp is reproduced exactly
+
+
+def test_prune2d_known_answers():
+    """Hand-checked cases of the keypoint pruning restatement (parity unpinned: the reference decides
+    these through cv2 rasterisers; see oracle/prune2d.py)."""
+    square = np.array([[10, 10], [20, 10], [20, 20], [10, 20]], np.int32)
+    assert prune2d.point_in_polygon(15.0, 15.0, square)
+    assert prune2d.point_in_polygon(10.0, 12.5, square)            # on an edge
+    assert prune2d.point_in_polygon(20.0, 20.0, square)            # on a corner
+    assert not prune2d.point_in_polygon(20.000001, 15.0, square)
+    assert not prune2d.point_in_polygon(5.0, 10.0, square)         # level with an edge, outside
+    assert not prune2d.point_in_polygon(0.0, 0.0, square)
+    bowtie = np.array([[0, 0], [10, 10], [10, 0], [0, 10]], np.int32)
+    assert prune2d.point_in_polygon(2.0, 5.0, bowtie) and prune2d.point_in_polygon(8.0, 5.0, bowtie)
+    assert not prune2d.point_in_polygon(5.0, 2.0, bowtie)
+    # a horizontal 5-pixel line paints 5 rows; its caps reach 2 pixels past the ends on the axis
+    src = np.zeros((224, 224), np.uint8)
+    prune2d.draw_band(src, (50, 100), (60, 100), 5)
+    assert np.array_equal(np.nonzero(src[:, 55])[0], np.arange(98, 103))
+    assert src[100, 48] == 255 and src[100, 47] == 0 and src[100, 62] == 255 and src[100, 63] == 0
+    assert src[98, 48] == 0 and src[99, 48] == 255 and src[98, 49] == 255    # cap: 1 + 4 <= 6.25 < 4 + 4
+    # 45 degrees: pixels at perpendicular distance 2.12 are in, 2.83 out
+    src[:] = 0
+    prune2d.draw_band(src, (10, 10), (40, 40), 5)
+    assert src[20, 23] == 255 and src[23, 20] == 255 and src[19, 23] == 0
+    # a chair facing right: left-side bones are drawn, right and centre bones are tested
+    rs = np.random.RandomState(0)
+    sparse = np.concatenate([rs.randint(0, 224, (10, 2)), np.ones((10, 1), int)], 1)
+    out = prune2d.make_dense_keypoints_image(sparse, "chair")
+    assert out.shape == (2, 130)
+    assert prune2d.make_dense_keypoints_image(np.zeros((10, 3)), "chair", dataset="pascal3D") is None
