@@ -13,6 +13,7 @@ depth_loc = os.path.join(synthetic_data_dir, "depth")
 syn_disparity_loc = os.path.join(synthetic_data_dir, "disparity")
 syn_dense_keypoint_loc = os.path.join(synthetic_data_dir, "dense_keypoints")
 g_save_file_location_final = os.path.join(synthetic_data_dir, "render_final")
+processed_image_loc = os.path.join(data_dir, "real_data")
 sample_points_loc = os.path.join(data_dir, "sample_points")
 g_datasets_folder = os.path.abspath(os.path.join(data_dir, "datasets"))
 g_shapenet_root_folder = os.path.join(g_datasets_folder, "ShapeNetCore/ShapeNetCore.v1")

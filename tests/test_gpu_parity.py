@@ -272,6 +272,44 @@ def test_script_entry_points_on_a_data_tree(pea, tmp_path, golden_geometry):
             setattr(gv, k, v)
 
 
+def test_real_image_script_on_a_data_tree(pea, tmp_path):
+    """make_dense_pointset.make_dense_keypoints over real_data/<dataset>/<class>/{images,sparse_keypoints}."""
+    from oracle import prune2d
+    gv = pea.global_variables
+    saved = (gv.processed_image_loc, gv.data_dir)
+    try:
+        gv.data_dir = str(tmp_path)
+        gv.processed_image_loc = str(tmp_path / "real_data")
+        rs = np.random.RandomState(8)
+        for dataset, stem, cls in (("keypoint-5", "sofa", "sofa"), ("pascal3D", "chair_pascal", "chair")):
+            root = tmp_path / "real_data" / dataset / stem
+            (root / "images").mkdir(parents=True)
+            (root / "sparse_keypoints").mkdir()
+            k = 14 if cls == "sofa" else 10
+            sparse = {}
+            for i in range(7):
+                name = "%08d_img" % i
+                (root / "images" / (name + ".jpg")).write_bytes(b"")
+                kp = np.concatenate([rs.uniform(-10, 240, (k, 2)), (rs.uniform(size=(k, 1)) < 0.8) * 1.0], 1)
+                if dataset == "pascal3D" and i == 2:
+                    kp[:, 2] = 0
+                np.save(root / "sparse_keypoints" / (name + ".npy"), kp)
+                sparse[name] = kp
+            n = pea.make_dense_pointset.make_dense_keypoints(dataset, cls, "pascal")
+            listed = (tmp_path / "image_lists" / "dense_keypoints" / f"{dataset}_{cls}_pascal.txt").read_text().split()
+            want = {name: prune2d.make_dense_keypoints_image(kp, cls, dataset) for name, kp in sparse.items()}
+            assert sorted(listed) == sorted(name for name, w in want.items() if w is not None) and n == len(listed)
+            for name, w in want.items():
+                path = root / "dense_keypoints" / (name + ".npy")
+                if w is None:
+                    assert not path.exists()
+                else:
+                    got = np.load(path)
+                    assert got.dtype == np.float64 and np.array_equal(got, w)
+    finally:
+        gv.processed_image_loc, gv.data_dir = saved
+
+
 def test_flow_splat_slice_semantics(pea):
     uv = np.array([[0, 1, 2, 223, 230, -5, 100, 50], [50, 50, 50, 223, 10, 60, -3, 50], [1.0] * 8])
     uv2 = uv + np.array([[1.5], [-2.0], [0.0]]) * np.arange(1, 9)
