@@ -63,3 +63,23 @@ def test_allgather_two_ranks_gloo(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+def test_allgather_device_tensors_one_rank_rccl(tmp_path):
+    """The exchange as the GPU job runs it: device tensors through RCCL (one rank is all a one-GPU
+    box can hold), synchronous and overlapped forms, in this process."""
+    sh = _load_sharding()
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        full = torch.arange(512 * 4096, dtype=torch.int32, device="cuda").reshape(512, 1, 4096)
+        assert torch.equal(sh.allgather_results(full.clone(), 512), full)
+        pend = [sh.allgather_results_async(full + k, 512) for k in (0, 7)]
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # work meanwhile
+        assert torch.equal(pend[0].wait(), full) and torch.equal(pend[1].wait(), full + 7)
+        assert torch.isfinite(busy).all()
+        with pytest.raises(ValueError):
+            sh.allgather_results(full[:100], 512)
+    finally:
+        dist.destroy_process_group()
