@@ -203,20 +203,20 @@ struct TopList {            // K+1 best scores, descending, each with its code
             // Most scores beat nobody's list: skip the update when no lane of the wave has a
             // candidate (the chance falls like 64 (K+1) / t with the position t in the stream).
             if (__builtin_amdgcn_ballot_w64(x > v[K]) == 0) return;
-            // replace the last entry if better, then bubble it up (branch-free)
-            const bool in = x > v[K];
-            v[K] = in ? x : v[K];
-            c[K] = in ? code : c[K];
+            // sorted insert, branch-free: slot s takes its upper neighbour if x goes above that one,
+            // x if x goes exactly here, else keeps its entry (x after equal scores: lower code first).
+            // Scores: one v_med3 per slot; codes: two selects per slot on the K+1 comparisons.
+            bool g[K + 1];
+#pragma unroll
+            for (int s = 0; s <= K; ++s) g[s] = x > v[s];
+            const float xs = g[K] ? x : kNegInf;         // a score that stays out (or a NaN) changes nothing
 #pragma unroll
             for (int s = K; s > 0; --s) {
-                const bool sw = v[s] > v[s - 1];
-                const float hi = sw ? v[s] : v[s - 1], lo = sw ? v[s - 1] : v[s];
-                const int chi = sw ? c[s] : c[s - 1], clo = sw ? c[s - 1] : c[s];
-                v[s - 1] = hi;
-                v[s] = lo;
-                c[s - 1] = chi;
-                c[s] = clo;
+                c[s] = g[s - 1] ? c[s - 1] : (g[s] ? code : c[s]);
+                v[s] = __builtin_amdgcn_fmed3f(xs, v[s - 1], v[s]);
             }
+            c[0] = g[0] ? code : c[0];
+            v[0] = fmaxf(xs, v[0]);
         }
     }
     __device__ __forceinline__ float value(int s) const { return v[s]; }
@@ -751,6 +751,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // reads behind it; callers wait with an explicit vmcnt.
 __device__ __forceinline__ void glds_b128(unsigned voff, uint64_t sbase, unsigned lds_dst) {
     unsigned keep;
+    // wave-uniform by construction; said explicitly so that the operands stay scalar registers
+    // whatever the optimiser concludes about the control flow around the call
+    // (the builtin returns int: widen through uint32_t, not by sign extension)
+    const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sbase >> 32));
+    const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sbase);
+    sbase = ((uint64_t)base_hi << 32) | (uint64_t)base_lo;
+    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
