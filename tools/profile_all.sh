@@ -30,6 +30,7 @@ run project --workload project &&
 run disparity --workload disparity &&
 run zbuffer --workload zbuffer &&
 run corr --workload corr &&
+run nn___config5_bf16_k5 --workload nn --dtype bf16 --grid 128 --channels 256 --k 5 --pairs 24 --no-extra &&
 sq nn___dtype_f32 --workload nn --dtype f32 &&
 sq nn___dtype_bf16 --workload nn --dtype bf16 &&
 sq nn___dtype_f32___filter_split --workload nn --dtype f32 --filter split &&
