@@ -80,6 +80,72 @@ __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict_
     for (int p = threadIdx.x; p < cells; p += 256) o[p] = o[p] / denom * 10.f;
 }
 
+// Large grids (a 128 x 128 map is 16 MB per item): corr_eccv_kernel would stream the whole first map
+// once per keypoint through a single CU.  Here one block owns 256 cells and all K <= 16 keypoints, so the
+// map is read once, by many CUs; the per-(b, k) normalisation runs afterwards (corr_eccv_scale_kernel)
+// with the same summation order as corr_eccv_kernel, and the dot products are the same fmaf chains,
+// so both paths give the same bits.
+constexpr int kEccvMaxK = 16;
+__global__ __launch_bounds__(256) void corr_eccv_tile_kernel(const float *__restrict__ f1r,
+                                                             const float *__restrict__ f2r,
+                                                             const int64_t *__restrict__ knn, int views, int C,
+                                                             int grid, int K, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // tm[c][16]: keypoint kk's channel c
+    const int b = blockIdx.y;
+    const int cells = grid * grid;
+    const int64_t base = (int64_t)b * C * cells;
+    const int64_t *kn = knn + (int64_t)(b % views) * K * 2;
+    for (int t = threadIdx.x; t < C * kEccvMaxK; t += 256) {
+        const int c = t >> 4, kk = t & 15;
+        float v = 0.f;
+        if (kk < K) v = f2r[base + (int64_t)c * cells + (int)kn[2 * kk + 1] * grid + (int)kn[2 * kk]];
+        sm[t] = v;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= cells) return;
+    float acc[kEccvMaxK];
+#pragma unroll
+    for (int kk = 0; kk < kEccvMaxK; ++kk) acc[kk] = 0.f;
+    const float *col = f1r + base + p;
+    const float4 *tm4 = reinterpret_cast<const float4 *>(sm);
+    const int groups = (K + 3) >> 2;
+    auto channel = [&](int c, float v) {
+#pragma unroll
+        for (int g = 0; g < kEccvMaxK / 4; ++g) {
+            if (g < groups) {
+                const float4 t = tm4[c * 4 + g];
+                acc[4 * g + 0] = fmaf(t.x, v, acc[4 * g + 0]);
+                acc[4 * g + 1] = fmaf(t.y, v, acc[4 * g + 1]);
+                acc[4 * g + 2] = fmaf(t.z, v, acc[4 * g + 2]);
+                acc[4 * g + 3] = fmaf(t.w, v, acc[4 * g + 3]);
+            }
+        }
+    };
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * cells];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) channel(c + u, v[u]);
+    }
+    for (; c < C; ++c) channel(c, col[(int64_t)c * cells]);
+#pragma unroll
+    for (int kk = 0; kk < kEccvMaxK; ++kk)
+        if (kk < K) out[((int64_t)b * K + kk) * cells + p] = fmaxf(acc[kk], 0.f);
+}
+
+// one block per (b, k): out[b][k][:] (relu'd correlations) / sum exp * 10, as corr_eccv_kernel ends
+__global__ __launch_bounds__(256) void corr_eccv_scale_kernel(float *__restrict__ out, int cells, int K) {
+    __shared__ float scratch[4];
+    float *o = out + ((int64_t)blockIdx.y * K + blockIdx.x) * cells;
+    float esum = 0.f;
+    for (int p = threadIdx.x; p < cells; p += 256) esum += expf(o[p]);
+    const float denom = block_sum(esum, scratch);
+    for (int p = threadIdx.x; p < cells; p += 256) o[p] = o[p] / denom * 10.f;
+}
+
 // one block per (b, 64 columns of the second map); all rows p of the first map
 __global__ __launch_bounds__(256) void corr_acmm_kernel(const float *__restrict__ f1r, const float *__restrict__ f2r,
                                                         const float *__restrict__ mask, int C, int grid, int H,
@@ -270,12 +336,26 @@ extern "C" int ispa_corr_map_eccv_views(const float *f1, const float *f2, const 
     ISPA_REQUIRE(f1 && f2 && knn && out && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int items = B * V;
-    float *f1r = workspace, *f2r = workspace + (int64_t)items * C * grid * grid;
-    if (int rc = launch_resize(f1, (int64_t)items * C, H, W, grid, grid, f1r, s)) return rc;
-    if (int rc = launch_resize(f2, (int64_t)items * C, H, W, grid, grid, f2r, s)) return rc;
+    const float *f1r = f1, *f2r = f2;
+    if (H != grid || W != grid) {
+        // (a map already at the grid's size is its own resize: weights 1 and 0 exactly)
+        float *r1 = workspace, *r2 = workspace + (int64_t)items * C * grid * grid;
+        if (int rc = launch_resize(f1, (int64_t)items * C, H, W, grid, grid, r1, s)) return rc;
+        if (int rc = launch_resize(f2, (int64_t)items * C, H, W, grid, grid, r2, s)) return rc;
+        f1r = r1;
+        f2r = r2;
+    }
+    const int cells = grid * grid;
+    const size_t tile_lds = (size_t)C * kEccvMaxK * sizeof(float);
     const ispa::TimingSlot timed = ispa::timing_begin(s);
-    hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, items), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, V, C,
-                       grid, K, out);
+    if (cells >= 2048 && K <= kEccvMaxK && tile_lds <= 64 * 1024) {
+        hipLaunchKernelGGL(corr_eccv_tile_kernel, dim3((cells + 255) / 256, items), dim3(256), tile_lds, s, f1r, f2r,
+                           knn, V, C, grid, K, out);
+        hipLaunchKernelGGL(corr_eccv_scale_kernel, dim3(K, items), dim3(256), 0, s, out, cells, K);
+    } else {
+        hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, items), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, V,
+                           C, grid, K, out);
+    }
     ispa::timing_end(timed, s);
     return ispa::check_launch("corr_eccv_kernel");
 }

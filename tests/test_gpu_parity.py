@@ -874,6 +874,29 @@ def test_corr_eccv_large_grid(pea):
     assert np.allclose(got, want, rtol=1e-4, atol=1e-9)
 
 
+def test_corr_eccv_tiled_and_single_block_paths_agree(pea):
+    """Large grids take the tiled kernel (up to 16 keypoints), anything else one block per keypoint:
+    same fmaf chains and the same summation order, so the maps must agree bit for bit; plus resized
+    inputs, a channel count off the unroll, several views, against the oracle."""
+    rs = np.random.RandomState(14)
+    f1 = _unit(rs, (2, 37, 96, 96))
+    f2 = _unit(rs, (2, 37, 96, 96))
+    knn17 = rs.randint(0, 48, (17, 2))
+    layer = pea.correspondence.CorrelationMapLayer(grid=48)              # 2304 cells, resized from 96 x 96
+    single = layer.forward(f1, f2, knn17)                                 # 17 keypoints: one block per keypoint
+    tiled = layer.forward(f1, f2, knn17[:16])
+    assert np.array_equal(single[:, :16], tiled)
+    assert np.allclose(tiled, ocorr.correlation_map_eccv(f1, f2, knn17[:16], grid=48), rtol=1e-4, atol=1e-9)
+    tiled3 = layer.forward(f1, f2, knn17[:3])
+    assert np.array_equal(single[:, :3], tiled3)
+    fi, fj = _unit(rs, (2, 3, 64, 64, 64)), _unit(rs, (2, 3, 64, 64, 64))
+    knn = rs.randint(0, 64, (3, 10, 2))
+    got = pea.correspondence.CorrelationMapLayer(grid=64).forward_views(fi, fj, knn)
+    for v in range(3):
+        want = ocorr.correlation_map_eccv(fi[:, v], fj[:, v], knn[v], grid=64)
+        assert np.allclose(got[:, v], want, rtol=1e-4, atol=1e-9)
+
+
 def test_resize_and_l2norm(pea, golden_correlation):
     z = golden_correlation
     got = pea.correspondence.resize_bilinear(z["resize_in"], (28, 28))
