@@ -2158,7 +2158,22 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     const int64_t want = 1024;
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
-    while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
+    if (p.bf16_mfma && p.ktemplate > 1) {
+        // A top-k stream pays a sorted insert for nearly every score of its first few hundred (measured:
+        // as much as ~800 further references would cost), so splitting is weighed against that: rounds
+        // of workgroups over the chip times (references per split + 800), smallest wins.
+        const int64_t slots = 256 * (C > 128 ? 1 : 2);
+        int64_t best_cost = -1;
+        for (int64_t n = 1; n == 1 || chunks / n >= 2; n *= 2) {
+            const int64_t cost = ((base * n + slots - 1) / slots) * ((chunks + n - 1) / n * chunk_refs + 800);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                nsplit = n;
+            }
+        }
+    } else {
+        while (base * nsplit < want && chunks / (nsplit * 2) >= 2) nsplit *= 2;
+    }
     const int64_t cps = (chunks + nsplit - 1) / nsplit;
     p.refs_per_split = cps * chunk_refs;
     p.nsplit = (int)((chunks + cps - 1) / cps);
