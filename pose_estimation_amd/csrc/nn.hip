@@ -1703,8 +1703,8 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         // Top-k, some margin too small.  Every reference that can be among the exact k nearest scores
         // at least lim = v[k-1] - delta.  A stream can hide an unkept reference above lim only if its
         // own last kept score reaches lim.  If no stream does, the contenders are the kept entries
-        // >= lim of all streams, known by index: re-score them in float64 (the oracle's channel
-        // order) and keep the k smallest (distance, index).
+        // >= lim of all streams, known by index: they are re-scored in float64 (the oracle's channel
+        // order) and the k smallest (distance, index) kept.
         const float lim = v[k_out - 1] - delta;
         bool hidden = false;
 #pragma unroll
@@ -1715,68 +1715,12 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             if (last != last || (last > kAbsent && last >= lim)) hidden = true;
         }
         if (!hidden) {
-            const T *qcol = q + (int64_t)b * C * nq + i;
-            const double qq_d = qq64[(int64_t)b * nq + i];
-            double cd[K];
-            int cj[K];
-#pragma unroll
-            for (int e = 0; e < K; ++e) {
-                cd[e] = __builtin_inf();
-                cj[e] = 0x7fffffff;
-            }
-            int nc = 0;
-            for (int p = 0; p < nparts && !hidden; ++p)
-                for (int s = 0; s < K; ++s) {
-                    const int64_t o = (((int64_t)b * nparts + p) * (K + 1) + s) * nq + i;
-                    const float x = part_val[o];
-                    if (!(x > kAbsent) || x < lim) break;       // a stream's list is descending
-                    const int j = part_idx[o];
-                    if (j < 0) {
-                        hidden = true;
-                        break;
-                    }
-                    const T *rcol = r + (int64_t)b * C * nr + j;
-                    double dot = 0.0;
-                    int c0 = 0;
-                    for (; c0 + 8 <= C; c0 += 8) {             // 16 loads in flight, then the ordered chain
-                        float qv[8], rv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
-                            rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
-                    }
-                    for (; c0 < C; ++c0)
-                        dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
-                                  (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
-                    // insert into the ascending (distance, index) list; what falls off the end is dropped
-                    double xd = (qq_d + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
-                    int xj = j;
-#pragma unroll
-                    for (int e = 0; e < K; ++e) {
-                        const bool lt = xd < cd[e] || (xd == cd[e] && xj < cj[e]);
-                        const double td = lt ? cd[e] : xd;
-                        const int tj = lt ? cj[e] : xj;
-                        cd[e] = lt ? xd : cd[e];
-                        cj[e] = lt ? xj : cj[e];
-                        xd = td;
-                        xj = tj;
-                    }
-                    ++nc;
-                }
-            if (!hidden && nc >= k_out) {
-#pragma unroll
-                for (int s = 0; s < K; ++s)
-                    if (s < k_out) {
-                        const int64_t o = ((int64_t)b * k_out + s) * nq + i;
-                        idx[o] = cj[s] + index_base;
-                        dist[o] = (float)cd[s];
-                    }
-                if (light_count) atomicAdd(light_count, 1);
-                return;
-            }
+            // known contenders: nn_rescore_topk_kernel settles the query, one wave per query (doing
+            // it here would make this one thread's dependent loads the duration of the whole kernel)
+            const int slot = atomicAdd(light_count, 1);
+            light_list[2 * slot] = (int)((int64_t)b * nq + i);
+            light_list[2 * slot + 1] = __float_as_int(lim);
+            return;
         }
     }
     // two queues: a global one (balanced one-query-per-block pass) and one per pair (the batched
@@ -1855,6 +1799,112 @@ __global__ __launch_bounds__(256) void nn_rescore_top1_kernel(const float *__res
         if (lane == 0) {                                 // k_out == 1
             idx[flat] = best_j + index_base;
             dist[flat] = (float)best_d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3c. top-k queries whose contenders are known: one wave per query.  Lane t looks at kept entry
+// t % K of stream t / K; entries that reach the query's limit are re-scored in float64 as above, and
+// the wave extracts the k smallest (distance, index) with k rounds of a wave-wide minimum.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ __launch_bounds__(256) void nn_rescore_topk_kernel(const float *__restrict__ part_val,
+                                                              const int *__restrict__ part_idx, int nparts,
+                                                              const T *__restrict__ q, const T *__restrict__ r,
+                                                              const double *__restrict__ qq64,
+                                                              const double *__restrict__ rr64, int C, int64_t nq,
+                                                              int64_t nr, int k_out, int index_base,
+                                                              const int *__restrict__ light_count,
+                                                              const int *__restrict__ light_list,
+                                                              float *__restrict__ dist, int *__restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int count = *light_count;
+    const int total = nparts * K;
+    for (int w = wave; w < count; w += nwaves) {
+        const int64_t flat = light_list[2 * w];
+        const float lim = __int_as_float(light_list[2 * w + 1]);
+        const int b = (int)(flat / nq);
+        const int64_t i = flat % nq;
+        const T *qcol = q + (int64_t)b * C * nq + i;
+        double cd[K];                                    // the wave's k smallest so far, same in every lane
+        int cj[K];
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            cd[e] = __builtin_inf();
+            cj[e] = 0x7fffffff;
+        }
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int j = -1;
+            if (t < total) {
+                const int64_t o = (((int64_t)b * nparts + t / K) * (K + 1) + t % K) * nq + i;
+                const float x = part_val[o];
+                if (x > kAbsent && x >= lim) j = part_idx[o];
+            }
+            double d = __builtin_inf();
+            int dj = 0x7fffffff;
+            if (j >= 0) {
+                const T *rcol = r + (int64_t)b * C * nr + j;
+                double dot = 0.0;
+                int c0 = 0;
+                for (; c0 + 16 <= C; c0 += 16) {
+                    float qv[16], rv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+                        rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+                }
+                for (; c0 < C; ++c0)
+                    dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
+                              (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
+                d = (qq64[flat] + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+                dj = j;
+            }
+            const int n_valid = __popcll(__builtin_amdgcn_ballot_w64(j >= 0));
+            const int rounds = n_valid < k_out ? n_valid : k_out;
+            for (int e = 0; e < rounds; ++e) {
+                double md = d;
+                int mj = dj;
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double od = __shfl_xor(md, off);
+                    const int oj = __shfl_xor(mj, off);
+                    if (od < md || (od == md && oj < mj)) {
+                        md = od;
+                        mj = oj;
+                    }
+                }
+                if (dj == mj) {                          // the owner retires it (a reference sits in one stream only)
+                    d = __builtin_inf();
+                    dj = 0x7fffffff;
+                }
+                // insert into the ascending (distance, index) list; what falls off the end is dropped
+                double xd = md;
+                int xj = mj;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const bool lt = xd < cd[s] || (xd == cd[s] && xj < cj[s]);
+                    const double td = lt ? cd[s] : xd;
+                    const int tj = lt ? cj[s] : xj;
+                    cd[s] = lt ? xd : cd[s];
+                    cj[s] = lt ? xj : cj[s];
+                    xd = td;
+                    xj = tj;
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < K; ++s)
+                if (s < k_out) {
+                    const int64_t o = ((int64_t)b * k_out + s) * nq + i;
+                    idx[o] = cj[s] + index_base;
+                    dist[o] = (float)cd[s];
+                }
         }
     }
 }
@@ -2410,6 +2460,15 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         hipLaunchKernelGGL((nn_rescore_top1_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval, pidx,
                            p.nparts, q, r, q64, r64, C, nq, nr, index_base, count + 1, llist, dist, idx);
         if (int rc = ispa::check_launch("nn_rescore_top1_kernel")) return rc;
+    } else {
+        const int64_t waves = (int64_t)B * nq < 4096 ? (int64_t)B * nq : 4096;
+#define ISPA_RESCORE_TOPK(KT)                                                                                  \
+    hipLaunchKernelGGL((nn_rescore_topk_kernel<T, KT>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval,  \
+                       pidx, p.nparts, q, r, q64, r64, C, nq, nr, k, index_base, count + 1, llist, dist, idx)
+        if (p.ktemplate == 5) ISPA_RESCORE_TOPK(5);
+        else ISPA_RESCORE_TOPK(kMaxK);
+#undef ISPA_RESCORE_TOPK
+        if (int rc = ispa::check_launch("nn_rescore_topk_kernel")) return rc;
     }
 
     // float64 pass: pairs with long queues (when queues are long on average) share one sweep over
