@@ -685,6 +685,28 @@ def test_nn_pointers_off_the_16_byte_grid(pea):
                     assert np.array_equal(i[p].cpu().numpy(), want_i), (mode, off, c)
 
 
+def test_nn_topk_contenders_spread_over_many_streams(pea):
+    """Few queries against a long reference map (many reference splits), with copies of one reference
+    scattered over the map: the exact ties sit in many partial streams and are settled by the
+    wave-per-query top-k re-scoring (more candidate slots than lanes for k = 8)."""
+    rs = np.random.RandomState(55)
+    for c, nq, nr in ((64, 16, 8192), (128, 8, 16384)):
+        q, r = _unit(rs, (2, c, nq)), _unit(rs, (2, c, nr))
+        spots = rs.choice(nr, 12, replace=False)
+        r[:, :, spots] = r[:, :, spots[:1]]
+        q[:, :, 0] = r[:, :, spots[0]]
+        q[:, :, 1] = r[:, :, spots[0]]
+        near = rs.choice(nr, 6, replace=False)             # and a cluster of near (not exact) ties
+        for t, j in enumerate(near):
+            r[0, :, j] = r[0, :, near[0]]
+            r[0, t, j] = np.nextafter(r[0, t, j], np.float32(2.0))
+        q[0, :, 2] = r[0, :, near[0]]
+        for k in (5, 8, 2):
+            for bf16 in (False, True):
+                st = _nn_check(pea, q, r, k, bf16=bf16)
+                assert st["candidate_rescores"] >= 2, (c, k, bf16, st)
+
+
 def test_nn_top5_c256(pea):
     rs = np.random.RandomState(12)
     _nn_check(pea, _unit(rs, (1, 256, 2048)), _unit(rs, (1, 256, 4096)), 5)
