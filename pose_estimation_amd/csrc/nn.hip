@@ -1916,12 +1916,13 @@ __device__ __forceinline__ bool key_less(double d0, int j0, double d1, int j1) {
     return d0 < d1 || (d0 == d1 && j0 < j1);
 }
 
-// One block per queued query.  d2(j) = (qq + rr_j) - 2 dot_j with dot accumulated over channels in
+// One block (NT threads: 1024 for long reference maps, where a single queued query would otherwise set the
+// duration of the launch) per queued query.  d2(j) = (qq + rr_j) - 2 dot_j with dot accumulated over channels in
 // increasing order in float64 (every product of two float32 values is exact in float64); qq and
 // rr come from the norms kernel, accumulated the same way.  Four references per thread are in
 // flight at a time so that the dependent fma chains overlap.
-template <typename T>
-__global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, const T *__restrict__ r,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void nn_exact_kernel(const T *__restrict__ q, const T *__restrict__ r,
                                                        const double *__restrict__ qq64,
                                                        const double *__restrict__ rr64, int C, int64_t nq,
                                                        int64_t nr, int k_out, int index_base, int vec_ok,
@@ -1931,9 +1932,9 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                                                        float *__restrict__ dist, int *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *qs = reinterpret_cast<double *>(smem);                 // C doubles
-    double *sd = qs + C;                                           // 256 doubles
-    int *sj = reinterpret_cast<int *>(sd + 256);                   // 256 ints
-    int *sown = sj + 256;                                          // 256 ints
+    double *sd = qs + C;                                           // NT doubles
+    int *sj = reinterpret_cast<int *>(sd + NT);                    // NT ints
+    int *sown = sj + NT;                                           // NT ints
     const int count = *amb_count;
     // pairs with long queues belong to nn_exact_top1_kernel, but only when queues are long on
     // average: sharing reference reads pays off in bandwidth, not in latency
@@ -1947,7 +1948,7 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
         const T *rb = r + (int64_t)b * C * nr;
         const double *rrb = rr64 + (int64_t)b * nr;
         __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) qs[c] = (double)load_as_float(qcol + (int64_t)c * nq);
+        for (int c = threadIdx.x; c < C; c += NT) qs[c] = (double)load_as_float(qcol + (int64_t)c * nq);
         __syncthreads();
         const double qq = qq64[flat];
         double bd[kMaxK];
@@ -1976,7 +1977,7 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
         constexpr int V = 16 / (int)sizeof(T);          // cells per 16-byte load: 4 float, 8 bfloat16
         if (vec_ok) {
             // V consecutive references per thread and load; every chain keeps the channel order
-            for (int64_t j0 = (int64_t)threadIdx.x * V; j0 < nr; j0 += 256 * V) {
+            for (int64_t j0 = (int64_t)threadIdx.x * V; j0 < nr; j0 += NT * V) {
                 double dot[V];
 #pragma unroll
                 for (int u = 0; u < V; ++u) dot[u] = 0.0;
@@ -2000,14 +2001,14 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                 for (int u = 0; u < V; ++u) consider(dot[u], (int)(j0 + u));
             }
         } else {
-            for (int64_t j0 = threadIdx.x; j0 < nr; j0 += 1024) {
+            for (int64_t j0 = threadIdx.x; j0 < nr; j0 += 4 * NT) {
                 double dot[4] = {0.0, 0.0, 0.0, 0.0};
                 const T *rp[4];
                 bool in[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    in[u] = j0 + 256 * u < nr;
-                    rp[u] = rb + (in[u] ? j0 + 256 * u : j0);
+                    in[u] = j0 + NT * u < nr;
+                    rp[u] = rb + (in[u] ? j0 + NT * u : j0);
                 }
                 for (int c = 0; c < C; ++c) {
                     const double qv = qs[c];
@@ -2017,7 +2018,7 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (in[u]) consider(dot[u], (int)(j0 + 256 * u));
+                    if (in[u]) consider(dot[u], (int)(j0 + NT * u));
             }
         }
         // k_out rounds of block-wide lexicographic minimum over the thread-local heads
@@ -2027,7 +2028,7 @@ __global__ __launch_bounds__(256) void nn_exact_kernel(const T *__restrict__ q, 
             sj[threadIdx.x] = bj[0];
             sown[threadIdx.x] = threadIdx.x;
             __syncthreads();
-            for (int off = 128; off > 0; off >>= 1) {
+            for (int off = NT / 2; off > 0; off >>= 1) {
                 if (threadIdx.x < off) {
                     const int o = threadIdx.x + off;
                     if (key_less(sd[o], sj[o], sd[threadIdx.x], sj[threadIdx.x])) {
@@ -2486,14 +2487,21 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     }
     const int64_t total_q = (int64_t)B * nq;
     const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096);
-    const size_t esmem = (size_t)C * sizeof(double) + 256 * (sizeof(double) + 2 * sizeof(int));
+    // (the split filter queues thousands of queries: throughput, not latency, so it keeps the small blocks)
+    const int ethreads = nr >= 8192 && !p.split ? 1024 : 256;
+    const size_t esmem = (size_t)C * sizeof(double) + ethreads * (sizeof(double) + 2 * sizeof(int));
     ISPA_REQUIRE(esmem <= 64 * 1024, "too many channels (%d) for the exact pass", C);
     // 16-byte loads of consecutive references need aligned rows
     const int evec = 16 / (int)sizeof(T);
     const int exact_vec_ok = nr % evec == 0 && (uintptr_t)r % 16 == 0;
-    hipLaunchKernelGGL((nn_exact_kernel<T>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr, k,
-                       index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount, dist,
-                       idx);
+    if (ethreads == 1024)
+        hipLaunchKernelGGL((nn_exact_kernel<T, 1024>), dim3(eblocks), dim3(1024), esmem, s, q, r, q64, r64, C, nq, nr,
+                           k, index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount,
+                           dist, idx);
+    else
+        hipLaunchKernelGGL((nn_exact_kernel<T, 256>), dim3(eblocks), dim3(256), esmem, s, q, r, q64, r64, C, nq, nr,
+                           k, index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount,
+                           dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
     if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;

@@ -707,6 +707,21 @@ def test_nn_topk_contenders_spread_over_many_streams(pea):
                 assert st["candidate_rescores"] >= 2, (c, k, bf16, st)
 
 
+def test_nn_full_rescans_on_long_reference_maps(pea):
+    """Long maps run the float64 pass with 1024-thread blocks: a run of identical references longer
+    than any kept list forces full rescans (aligned and odd map sizes, k = 1, 5, 8)."""
+    rs = np.random.RandomState(56)
+    for nr in (8192, 8197):
+        q, r = _unit(rs, (1, 64, 24)), _unit(rs, (1, 64, nr))
+        r[0, :, 4000:4100] = r[0, :, 4000:4001]
+        q[0, :, 0] = r[0, :, 4000]
+        q[0, :, 5] = r[0, :, 4000]
+        for k in (1, 5, 8):
+            for bf16 in (False, True):
+                st = _nn_check(pea, q, r, k, bf16=bf16)
+                assert st["full_rescans"] >= 2, (nr, k, bf16, st)
+
+
 def test_nn_top5_c256(pea):
     rs = np.random.RandomState(12)
     _nn_check(pea, _unit(rs, (1, 256, 2048)), _unit(rs, (1, 256, 4096)), 5)
