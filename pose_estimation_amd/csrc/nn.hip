@@ -2209,14 +2209,19 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     const int64_t want = 1024;
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
-    if (p.bf16_mfma && p.ktemplate > 1) {
-        // A top-k stream pays a sorted insert for nearly every score of its first few hundred (measured:
-        // as much as ~800 further references would cost), so splitting is weighed against that: rounds
-        // of workgroups over the chip times (references per split + 800), smallest wins.
+    // The LDS-staged float32 filter (four workgroups per CU) keeps the plain rule: about `want` workgroups.
+    const bool staged = !p.bf16_mfma && !p.split && !(p.ktemplate == 1 && C % 32 == 0 && C <= 128);
+    if (!staged) {
+        // The other filters hold two workgroups per CU up to 128 channels and one above, and every
+        // split stream pays a fixed price again: its query fragments and, for top-k, a sorted insert
+        // for nearly every score of its first few hundred (measured: what ~800 further references
+        // would cost; ~256 for top-1).  So: rounds of workgroups over the chip x (references per
+        // split + that price), smallest wins.
         const int64_t slots = 256 * (C > 128 ? 1 : 2);
+        const int64_t warm = p.ktemplate > 1 ? 800 : 256;
         int64_t best_cost = -1;
         for (int64_t n = 1; n == 1 || chunks / n >= 2; n *= 2) {
-            const int64_t cost = ((base * n + slots - 1) / slots) * ((chunks + n - 1) / n * chunk_refs + 800);
+            const int64_t cost = ((base * n + slots - 1) / slots) * ((chunks + n - 1) / n * chunk_refs + warm);
             if (best_cost < 0 || cost < best_cost) {
                 best_cost = cost;
                 nsplit = n;
