@@ -185,14 +185,15 @@ int ispa_resize_bilinear(const float *in, int B, int C, int H, int W, int oh, in
  *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:181-231
  * f1 (real), f2 (template): (B,C,H,W) f32; knn (K,2) int64 [x,y] on the grid x grid lattice.
  * out (B,K,grid,grid) f32 = relu(corr) / sum_yx exp(relu(corr)) * 10.
- * workspace: 2*B*C*grid*grid floats. */
+ * workspace: 2*B*C*grid*grid floats (the resized maps); not used and may be NULL when H == W == grid. */
 int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
                        int W, int K, int grid, float *out, float *workspace, void *stream);
 
 /* The per-view loop of eccv_net.Net.forward around that layer, in one call
  *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:282-289 (loop, stack, permute)
  * f1, f2 (B,V,C,H,W) f32; knn (V,K,2) int64, one keypoint list per view; out (B,V,K,grid,grid) f32,
- * which is the reference's `embedding` before its .view().  workspace: 2*B*V*C*grid*grid floats. */
+ * which is the reference's `embedding` before its .view().  workspace: 2*B*V*C*grid*grid floats (may be NULL when
+ * H == W == grid). */
 int ispa_corr_map_eccv_views(const float *f1, const float *f2, const int64_t *knn, int B, int V, int C, int H,
                              int W, int K, int grid, float *out, float *workspace, void *stream);
 

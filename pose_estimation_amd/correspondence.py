@@ -175,7 +175,7 @@ class CorrelationMapLayer:
         b, c, h, w = f1.shape
         k = knn.shape[0]
         out = dv.empty((b, k, self.grid, self.grid), torch.float32)
-        ws = _workspace(2 * b * c * self.grid * self.grid * 4)
+        ws = None if (h, w) == (self.grid, self.grid) else _workspace(2 * b * c * self.grid * self.grid * 4)
         _abi.check(_abi.lib.ispa_corr_map_eccv(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, c, h, w, k, self.grid,
                                                dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
         return dv.back(out, as_tensor)
@@ -205,7 +205,7 @@ class CorrelationMapLayer:
             raise ValueError("knn_inds must be (V,K,2)")
         k = knn.shape[1]
         out = dv.empty((b, v, k, self.grid, self.grid), torch.float32)
-        ws = _workspace(2 * b * v * c * self.grid * self.grid * 4)
+        ws = None if (h, w) == (self.grid, self.grid) else _workspace(2 * b * v * c * self.grid * self.grid * 4)
         _abi.check(_abi.lib.ispa_corr_map_eccv_views(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, v, c, h, w, k, self.grid,
                                                      dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
         return dv.back(out, as_tensor)

@@ -333,7 +333,8 @@ extern "C" int ispa_corr_map_eccv_views(const float *f1, const float *f2, const 
     ISPA_REQUIRE(grid <= 4096, "grid %d too large", grid);
     ISPA_REQUIRE(C <= 8192 && (int64_t)B * V <= 65535, "C or B x V too large");
     if (B == 0 || K == 0) return ISPA_OK;
-    ISPA_REQUIRE(f1 && f2 && knn && out && workspace, "null pointer");
+    ISPA_REQUIRE(f1 && f2 && knn && out, "null pointer");
+    ISPA_REQUIRE(workspace || (H == grid && W == grid), "workspace is null but the maps need resizing");
     hipStream_t s = (hipStream_t)stream;
     const int items = B * V;
     const float *f1r = f1, *f2r = f2;
