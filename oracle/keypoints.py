@@ -2,7 +2,8 @@
 
 Restates (from source text; the modules need cv2 / scipy.io / OpenEXR to import)
   data_creator/utils.py:192-251,352-374
-  data_creator/global_variables.py:55-71
+  data_creator/global_variables.py:55-71 (the tables are pinned against the imported module
+      through tests/golden/tables.json)
   data_creator/make_dense_pointset_syn.py:27-67
   data_creator/make_dense_pointset.py:70-77 (2-D linspace only)
   classifier_code/train_test_scripts/utils/io_utils.py:20-31,126-148
@@ -35,6 +36,11 @@ SKELETON_MAP = {
               [1, 8], [8, 7], [7, 0], [15, 16], [16, 17]],
              ["L", "R", "RR", "LL", "C", "R", "C", "L", "L", "C", "R", "C", "L", "L", "L", "R", "R",
               "R", "LL", "C", "RR", "O", "C", "C"], [3, 10, 9, 2]),
+    "car": ([[3, 16], [4, 17], [21, 34], [22, 35], [1, 3], [3, 4], [4, 6], [6, 17], [17, 16], [16, 1],
+             [19, 21], [21, 22], [22, 24], [24, 35], [35, 34], [34, 19], [1, 19], [3, 21], [4, 22],
+             [6, 24]],
+            ["LL", "LL", "RR", "RR", "L", "L", "L", "LL", "LL", "LL", "R", "R", "R", "RR", "RR", "RR",
+             "C", "C", "C", "C"], [3, 4, 21, 22]),
 }
 SKELETON_MAP["diningtable"] = SKELETON_MAP["table"]
 

@@ -31,6 +31,7 @@ LEG_RANGE = {                                            # global_variables.py:7
     "chair": list(range(40)), "swivelchair": list(range(40)),
     "bed": list(range(40)) + list(range(110, 140)), "table": list(range(40)),
     "diningtable": list(range(40)), "sofa": list(range(40)) + list(range(110, 120)),
+    "car": list(range(40)) + list(range(70, 100)) + list(range(130, 160)),
 }
 _PASCAL_EXTRA = {"chair": 4, "swivelchair": 4, "diningtable": 4, "bed": 7, "sofa": 4}   # utils.py:253-270
 

@@ -28,8 +28,12 @@ skeleton_map = {
               [15, 14], [6, 4], [4, 5], [5, 3], [13, 11], [11, 12], [12, 10], [0, 1], [1, 8], [8, 7], [7, 0],
               [15, 16], [16, 17]],
              "L R RR LL C R C L L C R C L L L R R R LL C RR O C C".split(), [3, 10, 9, 2]),
+    "car": ([[3, 16], [4, 17], [21, 34], [22, 35], [1, 3], [3, 4], [4, 6], [6, 17], [17, 16], [16, 1], [19, 21],
+             [21, 22], [22, 24], [24, 35], [35, 34], [34, 19], [1, 19], [3, 21], [4, 22], [6, 24]],
+            "LL LL RR RR L L L LL LL LL R R R RR RR RR C C C C".split(), [3, 4, 21, 22]),
 }
-skeleton_map["diningtable"] = skeleton_map["table"]
+skeleton_map["diningtable"] = (skeleton_map["table"][0], list(skeleton_map["table"][1]), skeleton_map["table"][2])
+skeleton_size = {"chair": 10, "swivelchair": 13, "table": 8, "sofa": 14, "bed": 10}   # global_variables.py:55
 
 # extra anchors = midpoint (nanmean) of two annotated anchors -- utils.py:199-251
 _midpoint_pairs = {
@@ -43,7 +47,8 @@ POINTS_PER_BONE = 10
 
 # dense-point columns tested against the seat outline -- global_variables.py:73-74
 leg_range = {"chair": range(40), "swivelchair": range(40), "bed": list(range(40)) + list(range(110, 140)),
-             "table": range(40), "diningtable": range(40), "sofa": list(range(40)) + list(range(110, 120))}
+             "table": range(40), "diningtable": range(40), "sofa": list(range(40)) + list(range(110, 120)),
+             "car": list(range(40)) + list(range(70, 100)) + list(range(130, 160))}
 img_size = (224, 224)                                    # global_variables.py:75
 _pascal_extra = {"chair": 4, "swivelchair": 4, "diningtable": 4, "bed": 7, "sofa": 4}   # utils.py:253-270
 LINE_THICKNESS = 5                                       # utils.py:314

@@ -27,3 +27,15 @@ def golden_disparity():
 @pytest.fixture(scope="session")
 def golden_correlation():
     return np.load(os.path.join(GOLDEN, "correlation.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_correlation_acmm():
+    return np.load(os.path.join(GOLDEN, "correlation_acmm.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tables():
+    import json
+    with open(os.path.join(GOLDEN, "tables.json")) as fh:
+        return json.load(fh)

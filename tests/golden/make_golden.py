@@ -11,6 +11,12 @@ What is imported from the reference, unmodified:
   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py -> CorrelationMapLayer.forward,
       called unbound on CPU with a stub `self` that only carries `down1` (the class
       constructor calls .cuda()).
+  classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py -> CorrelationMapLayer.forward,
+      called unbound on CPU the same way; the stub's `inception00` / `bn00` (the trained trunk
+      behind the correlation, lines 63-64) are identities, and torch.Tensor.cuda is patched to
+      return the tensor itself for the duration of the call (line 38 calls it on the mask).
+  data_creator/global_variables.py -> skeleton_map, leg_range, syn_template, img_size,
+      skeleton_size (the module imports nothing but os); written as tables.json.
 What cannot be imported here (cv2 / trimesh / OpenEXR / caffe missing) and is therefore
 re-typed below on top of the imported primitives, following the cited lines:
   run_proj.get_3d_to_2d / prune_pts (run_proj.py:24-46), make_disparity's body
@@ -306,8 +312,67 @@ def gen_correlation():
     print("correlation.npz", len(out), "arrays")
 
 
+def gen_acmm():
+    import torch
+    sys.path.insert(0, f"{REF}/classifier_code")
+    acmm = importlib.import_module("train_test_scripts.arch.acmm_net.net_final_old")
+    stub = types.SimpleNamespace(down1=torch.nn.UpsamplingBilinear2d(size=(28, 28)),
+                                 inception00=lambda x: x, bn00=lambda x: x)
+    out = {}
+    rs = np.random.RandomState(13)
+    for tag, (b, c) in {"b1c128": (1, 128), "b2c32": (2, 32)}.items():
+        f1 = rs.randn(b, c, 56, 56).astype(np.float32)
+        f2 = rs.randn(b, c, 56, 56).astype(np.float32)
+        f1 /= np.sqrt((f1 ** 2).sum(1, keepdims=True))
+        f2 /= np.sqrt((f2 ** 2).sum(1, keepdims=True))
+        # grid cell (0,0) of the last item samples source cell (0,0) alone: an all-zero feature2
+        # vector there makes the whole correlation column zero -> 0/0 = NaN in the reference
+        f2[b - 1, :, 0:2, 0:2] = 0
+        mask = (rs.uniform(size=(b, 1, 56, 56)) > 0.4).astype(np.float32)
+        f1 = f1.astype(np.float16)                      # stored compactly; these ARE the inputs
+        f2 = f2.astype(np.float16)
+        orig_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            with torch.no_grad():
+                res = acmm.CorrelationMapLayer.forward(stub, torch.from_numpy(f1.astype(np.float32)),
+                                                       torch.from_numpy(f2.astype(np.float32)),
+                                                       torch.from_numpy(mask))
+        finally:
+            torch.Tensor.cuda = orig_cuda
+        res = np.asarray(res.data if hasattr(res, "data") else res)
+        assert res.shape == (b, 784, 28, 28) and np.isnan(res[b - 1, :, 0, 0]).all()
+        out[f"{tag}_f1"] = f1
+        out[f"{tag}_f2"] = f2
+        out[f"{tag}_mask"] = mask.astype(np.uint8)
+        out[f"{tag}_out"] = res.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "correlation_acmm.npz"), **out)
+    print("correlation_acmm.npz", len(out), "arrays")
+
+
+def gen_tables():
+    import json
+    cwd = os.getcwd()
+    gv = _load("ref_global_variables", f"{REF}/data_creator/global_variables.py")
+    os.chdir(cwd)
+    tables = {
+        "skeleton_map": {k: [[list(b) for b in v[0]], list(v[1]), list(v[2])] for k, v in gv.skeleton_map.items()},
+        "leg_range": {k: [int(i) for i in v] for k, v in gv.leg_range.items()},
+        "syn_template": {k: list(v) for k, v in gv.syn_template.items()},
+        "img_size": list(gv.img_size),
+        "skeleton_size": dict(gv.skeleton_size),
+    }
+    with open(os.path.join(HERE, "tables.json"), "w") as fh:
+        json.dump(tables, fh, indent=1, sort_keys=True)
+    print("tables.json", {k: len(v) for k, v in tables.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "disparity", "correlation"]
+    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables"]
+    if "acmm" in which:
+        gen_acmm()
+    if "tables" in which:
+        gen_tables()
     if "geometry" in which:
         gen_geometry()
     if "disparity" in which:

@@ -959,6 +959,36 @@ def test_corr_acmm(pea, golden_correlation):
     assert np.isnan(got[:, :, 0, 0]).all() and np.isfinite(got[:, :, 20, 20]).all()
 
 
+@pytest.mark.parametrize("tag", ["b1c128", "b2c32"])
+def test_corr_acmm_golden(pea, golden_correlation_acmm, tag):
+    """Against net_final_old.py:33-61 itself (run on CPU by tests/golden/make_golden.py), NaN column included."""
+    z = golden_correlation_acmm
+    f1 = z[f"{tag}_f1"].astype(np.float32)
+    f2 = z[f"{tag}_f2"].astype(np.float32)
+    got = pea.correspondence.correlation_map_acmm(f1, f2, z[f"{tag}_mask"].astype(np.float32))
+    want = z[f"{tag}_out"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got[-1, :, 0, 0]).all()
+    # 1e-4 relative (float32 bar); entries near the relu threshold are cancellation residues of a 128-term
+    # signed sum whose summation-order error is absolute (1e-7 on maps whose entries are <= 1)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-6, equal_nan=True)
+
+
+def test_tables_on_the_device_side_equal_the_reference(pea, golden_tables):
+    t = golden_tables
+    dp = pea.dense_pointset
+    assert set(dp.skeleton_map) == set(t["skeleton_map"])
+    for cls, (bones, tags, seat) in t["skeleton_map"].items():
+        o = dp.skeleton_map[cls]
+        assert [list(b) for b in o[0]] == bones and list(o[1]) == tags and list(o[2]) == seat
+    assert {k: list(v) for k, v in dp.leg_range.items()} == t["leg_range"]
+    assert {k: list(v) for k, v in pea.global_variables.syn_template.items()} == t["syn_template"]
+    # the class the tables used to lack: 36 anchors, 20 bones -> 200 dense points
+    anchors = np.random.RandomState(4).uniform(-0.3, 0.3, (36, 3))
+    dense = dp.dense_skeleton(dp.get_additional_coords_keypoint_5(anchors.T, "car"), "car")
+    assert dense.shape == (3, 200) and np.array_equal(dense, okp.dense_skeleton_3d(anchors, "car"))
+
+
 def test_dense_keypoints(pea, golden_geometry, golden_disparity):
     anchors = golden_geometry["g2_anchor_chair"]
     depth = golden_disparity["rb_chair_depth"]
@@ -974,7 +1004,7 @@ def test_real_image_keypoint_pruning(pea):
     dataset modes, against the sequential restatement; then the three passes one by one."""
     from oracle import prune2d
     rs = np.random.RandomState(31)
-    n_sparse = {"chair": 10, "swivelchair": 13, "bed": 10, "table": 8, "diningtable": 12, "sofa": 14}
+    n_sparse = {"chair": 10, "swivelchair": 13, "bed": 10, "table": 8, "diningtable": 12, "sofa": 14, "car": 36}
     total_pruned = 0
     for cls, k in n_sparse.items():
         for dataset in ("keypoint-5", "pascal3D"):
@@ -982,7 +1012,7 @@ def test_real_image_keypoint_pruning(pea):
                 if cls == "table":
                     continue                     # the pascal extender has no 'table' branch: too few anchors
                 k_eff = max(b for bone in pea.dense_pointset.skeleton_map[cls][0] for b in bone) + 1 - \
-                    pea.dense_pointset._pascal_extra[cls]
+                    pea.dense_pointset._pascal_extra.get(cls, 0)
             else:
                 if cls == "diningtable":
                     continue                     # keypoint-5 has no midpoints for it: the bones index past K

@@ -161,6 +161,55 @@ def test_bilinear_resize(golden_correlation):
     assert np.allclose(got, z["resize_out"], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["b1c128", "b2c32"])
+def test_correlation_acmm_golden(golden_correlation_acmm, tag):
+    """net_final_old.py:33-61 run unmodified on CPU (stub self) pins the restatement, NaN column included."""
+    z = golden_correlation_acmm
+    f1 = z[f"{tag}_f1"].astype(np.float32)
+    f2 = z[f"{tag}_f2"].astype(np.float32)
+    got = correlation.correlation_map_acmm(f1, f2, z[f"{tag}_mask"].astype(np.float32))
+    want = z[f"{tag}_out"]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want[-1, :, 0, 0]).all()
+    # a correlation is a sum of 128 signed products of unit-vector components: entries near the relu
+    # threshold are cancellation residues, whose float32 summation-order error (1e-7) is absolute
+    assert np.allclose(got, want, rtol=1e-5, atol=5e-7, equal_nan=True)
+
+
+def test_tables_equal_the_imported_reference(golden_tables):
+    """skeleton_map / leg_range / syn_template / img_size as data_creator/global_variables.py holds them
+    (written by tests/golden/make_golden.py from the imported module) against both typed copies."""
+    import ast
+    import os
+    t = golden_tables
+    assert set(kp.SKELETON_MAP) == set(t["skeleton_map"]) and "car" in t["skeleton_map"]
+    for cls, (bones, tags, seat) in t["skeleton_map"].items():
+        o = kp.SKELETON_MAP[cls]
+        assert [list(b) for b in o[0]] == bones and list(o[1]) == tags and list(o[2]) == seat, cls
+    assert {k: list(v) for k, v in prune2d.LEG_RANGE.items()} == t["leg_range"]
+    # the product's copies: read as literals from the source files (importing the package needs the HIP library)
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pose_estimation_amd")
+
+    def module_values(path, names):
+        env = {}
+        tree = ast.parse(open(path).read())
+        for node in tree.body:
+            if isinstance(node, ast.Assign) and any(getattr(tg, "id", None) in names or
+                                                    (isinstance(tg, ast.Subscript) and getattr(tg.value, "id", None) in names)
+                                                    for tg in node.targets):
+                exec(compile(ast.Module([node], []), path, "exec"), env)
+        return env
+    env = module_values(os.path.join(root, "dense_pointset.py"), {"skeleton_map", "leg_range", "img_size", "skeleton_size"})
+    assert set(env["skeleton_map"]) == set(t["skeleton_map"])
+    for cls, (bones, tags, seat) in t["skeleton_map"].items():
+        o = env["skeleton_map"][cls]
+        assert [list(b) for b in o[0]] == bones and list(o[1]) == tags and list(o[2]) == seat, cls
+    assert {k: list(v) for k, v in env["leg_range"].items()} == t["leg_range"]
+    assert list(env["img_size"]) == t["img_size"] and env["skeleton_size"] == t["skeleton_size"]
+    env = module_values(os.path.join(root, "global_variables.py"), {"syn_template"})
+    assert {k: list(v) for k, v in env["syn_template"].items()} == t["syn_template"]
+
+
 def test_acmm_shares_contraction_with_eccv(golden_correlation):
     z = golden_correlation
     f1 = z["b2k10_f1"].astype(np.float32)
