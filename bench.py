@@ -50,6 +50,9 @@ def parse():
                     help="f32 only: 'split' runs the filter pass on bfloat16 MFMAs over a hi/lo split of the "
                          "float32 inputs (same exact results)")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step result all-gather")
+    ap.add_argument("--matches", action="store_true",
+                    help="nn: queries are noisy copies of (permuted) template cells, as for two views of one object: "
+                         "every nearest distance is small, so every returned distance takes the float64 refinement")
     ap.add_argument("--morton", action="store_true",
                     help="geometry workloads: put the model points in Morton order first (run_proj.spatial_order), "
                          "so that neighbouring lanes hit neighbouring pixels")
@@ -391,6 +394,11 @@ def main():
         x = torch.randn(b, c, g, g, device=dev, generator=gen)
         return (x / x.norm(dim=1, keepdim=True)).to(tdt).contiguous()
     q, r = feats(), feats()
+    if args.matches:
+        perm = torch.stack([torch.randperm(n, device=dev, generator=gen) for _ in range(b)])
+        q = torch.gather(r.float().view(b, c, n), 2, perm[:, None, :].expand(-1, c, -1)).view(b, c, g, g)
+        q = q + 0.02 * torch.randn(b, c, g, g, device=dev, generator=gen)
+        q = (q / q.norm(dim=1, keepdim=True)).to(tdt).contiguous()
     # gloo cannot all-gather device tensors: the rehearsal backend runs without the result exchange
     gather = world > 1 and not args.no_gather and args.backend == "nccl"
     filt = args.filter if args.dtype == "f32" else "native"
@@ -526,6 +534,7 @@ def main():
                                    + ("float32 inputs, split-bfloat16 MFMA filter" if filt == "split"
                                       else f"{args.dtype} MFMA filter") + " + float64 exact pass)",
                        "pairs_per_gpu": b, "grid": g, "channels": c, "k": args.k,
+                       "features": "queries = noisy copies of template cells" if args.matches else "independent random unit vectors",
                        "result_allgather": bool(gather)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),

@@ -44,6 +44,8 @@ constexpr int kMaxK = 8;
 // that it survives the mantissa tagging below; anything under kAbsent counts as "no entry".
 constexpr float kNegInf = -3.0e38f;
 constexpr float kAbsent = -1.0e38f;
+// A distance entry that nn_finalize_kernel leaves for nn_refine_kernel: a NaN bit pattern no arithmetic produces.
+constexpr uint32_t kRefineMark = 0x7fc5a5a5u;
 
 // Blocks b and b+8 share an XCD (and its L2).  Renumber so that each XCD walks a contiguous range
 // of logical ids: the query tiles of one image pair, which all stream the same reference map, then
@@ -56,6 +58,30 @@ __device__ __forceinline__ int xcd_order(int bid, int nblocks) {
 __device__ __forceinline__ float load_as_float(const float *p) { return *p; }
 __device__ __forceinline__ float load_as_float(const uint16_t *p) {
     return __uint_as_float(((uint32_t)*p) << 16);
+}
+
+// Squared distance of one (query column, reference column) pair in the CPU oracle's arithmetic:
+// (qq + rr) - 2 dot, dot accumulated over channels in increasing order in float64 (a product of two
+// float32 values is exact in float64), qq and rr from the norms kernel, accumulated the same way.  Two
+// identical columns give exactly 0.  16 channels of loads are in flight at a time.
+template <typename T>
+__device__ __forceinline__ double exact_d2(const T *__restrict__ qcol, const T *__restrict__ rcol, int C, int64_t nq,
+                                           int64_t nr, double qq, double rr) {
+    double dot = 0.0;
+    int c0 = 0;
+    for (; c0 + 16 <= C; c0 += 16) {
+        float qv[16], rv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+            rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+    }
+    for (; c0 < C; ++c0)
+        dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq), (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
+    return (qq + rr) - 2.0 * dot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1661,11 +1687,27 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         if (v[s + 1] > kAbsent && !(v[s] - v[s + 1] > delta)) sure = false;
     }
     if (sure) {
-        for (int s = 0; s < k_out; ++s) {
+        // Distance of a kept neighbour.  The filter score s carries an error of at most delta / 2 (delta
+        // bounds the difference of two scores), so qq - 2 s is within err = delta + 2^-22 qq of the exact
+        // squared distance d (the second term: float32 roundings of qq and of the subtraction).  Where
+        // that is provably under 1e-4 d, i.e. qq - 2 s >= 10002 err, it is returned; otherwise (close
+        // matches: the cancellation in |q|^2 + |r|^2 - 2 q.r eats the digits) the entry is marked and
+        // nn_refine_kernel recomputes the distance as the float64 pass computes it.
+        const float err = delta + 2.4e-7f * qq;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (s >= k_out) break;
             const int64_t o = ((int64_t)b * k_out + s) * nq + i;
-            const bool have = v[s] > kAbsent && c[s] >= 0;
-            idx[o] = have ? c[s] + index_base : -1;
-            dist[o] = have ? qq - 2.f * v[s] : __builtin_inff();
+            const bool have = v[s] > kAbsent && c[s] >= 0;      // k_out <= K
+            float d = __builtin_inff();
+            int j = -1;
+            if (have) {
+                j = c[s];
+                d = qq - 2.f * v[s];
+                if (!(d >= 10002.f * err)) d = __uint_as_float(kRefineMark);   // nn_refine_kernel recomputes it
+            }
+            idx[o] = have ? j + index_base : -1;
+            dist[o] = d;
         }
         return;
     }
@@ -1766,23 +1808,7 @@ __global__ __launch_bounds__(256) void nn_rescore_top1_kernel(const float *__res
                 if (part_val[o] >= lim) j = part_idx[o];
             }
             if (j < 0) continue;
-            const T *rcol = r + (int64_t)b * C * nr + j;
-            double dot = 0.0;
-            int c0 = 0;
-            for (; c0 + 16 <= C; c0 += 16) {
-                float qv[16], rv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
-                    rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
-            }
-            for (; c0 < C; ++c0)
-                dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq), (double)load_as_float(rcol + (int64_t)c0 * nr),
-                          dot);
-            const double d = (qq64[flat] + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+            const double d = exact_d2(qcol, r + (int64_t)b * C * nr + j, C, nq, nr, qq64[flat], rr64[(int64_t)b * nr + j]);
             if (d < best_d || (d == best_d && j < best_j)) {
                 best_d = d;
                 best_j = j;
@@ -1846,23 +1872,7 @@ __global__ __launch_bounds__(256) void nn_rescore_topk_kernel(const float *__res
             double d = __builtin_inf();
             int dj = 0x7fffffff;
             if (j >= 0) {
-                const T *rcol = r + (int64_t)b * C * nr + j;
-                double dot = 0.0;
-                int c0 = 0;
-                for (; c0 + 16 <= C; c0 += 16) {
-                    float qv[16], rv[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
-                        rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
-                }
-                for (; c0 < C; ++c0)
-                    dot = fma((double)load_as_float(qcol + (int64_t)c0 * nq),
-                              (double)load_as_float(rcol + (int64_t)c0 * nr), dot);
-                d = (qq64[flat] + rr64[(int64_t)b * nr + j]) - 2.0 * dot;
+                d = exact_d2(qcol, r + (int64_t)b * C * nr + j, C, nq, nr, qq64[flat], rr64[(int64_t)b * nr + j]);
                 dj = j;
             }
             const int n_valid = __popcll(__builtin_amdgcn_ballot_w64(j >= 0));
@@ -1907,6 +1917,115 @@ __global__ __launch_bounds__(256) void nn_rescore_topk_kernel(const float *__res
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3d. distances of close matches.  nn_finalize_kernel marks the entries whose filter score cannot give
+// the distance to 1e-4 relative; here they are recomputed in float64 (exact_d2).  One 1024-thread block
+// per (slice of kRefineEntries result entries, pair); entry e = s * nq + i is neighbour s of query i.
+//   few marked entries in the slice: each is re-scored straight from global memory (C scattered loads);
+//   many (good matches everywhere, the realistic case for corresponding images): the pair's reference map
+//   passes through LDS a group of channels at a time, every thread keeps float64 dot products for its
+//   entries and gathers the reference values from LDS: the map is read once per slice instead of one
+//   64-byte sector per (entry, channel).
+// Channel order is increasing either way, so both routes return the float64 pass's bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRefineThreads = 1024;
+constexpr int kRefinePer = 8;                                   // entries per thread
+constexpr int kRefineEntries = kRefineThreads * kRefinePer;
+constexpr int kRefineLds = 128 * 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kRefineThreads) void nn_refine_kernel(const T *__restrict__ q, const T *__restrict__ r,
+                                                                   const double *__restrict__ qq64,
+                                                                   const double *__restrict__ rr64, int C, int64_t nq,
+                                                                   int64_t nr, int k_out, int index_base, int vec_ok,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ dist) {
+    extern __shared__ __align__(16) unsigned char refine_lds[];
+    __shared__ int n_marked;
+    const int b = blockIdx.y;
+    const int64_t total = (int64_t)k_out * nq, e0 = (int64_t)blockIdx.x * kRefineEntries;
+    const T *qb = q + (int64_t)b * C * nq, *rb = r + (int64_t)b * C * nr;
+    if (threadIdx.x == 0) n_marked = 0;
+    __syncthreads();
+    int64_t qi[kRefinePer];
+    int rj[kRefinePer];
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < kRefinePer; ++u) {
+        const int64_t e = e0 + threadIdx.x + (int64_t)u * kRefineThreads;
+        rj[u] = -1;
+        qi[u] = 0;
+        if (e < total) {
+            const int64_t o = (int64_t)b * total + e;
+            if (__float_as_uint(dist[o]) == kRefineMark) {
+                const int j = idx[o] - index_base;
+                if (j >= 0 && j < nr) {                         // always true for an entry finalize marked
+                    rj[u] = j;
+                    qi[u] = e % nq;
+                    ++mine;
+                }
+            }
+        }
+    }
+    if (mine) atomicAdd(&n_marked, mine);
+    __syncthreads();
+    const int marked = n_marked;
+    if (marked == 0) return;
+    // LDS route: worth it once the scattered loads (a 64-byte sector each) would move more than the map
+    const int64_t row = (nr + 7) / 8 * 8;                       // elements per staged channel row
+    const int group = (int)(kRefineLds / (row * (int64_t)sizeof(T)) < C ? kRefineLds / (row * (int64_t)sizeof(T)) : C);
+    const bool sweep = group >= 1 && (int64_t)marked * 64 > nr * (int64_t)sizeof(T);
+    double dot[kRefinePer];
+#pragma unroll
+    for (int u = 0; u < kRefinePer; ++u) dot[u] = 0.0;
+    if (!sweep) {
+#pragma unroll
+        for (int u = 0; u < kRefinePer; ++u)
+            if (rj[u] >= 0) {
+                const int64_t o = (int64_t)b * total + e0 + threadIdx.x + (int64_t)u * kRefineThreads;
+                dist[o] = (float)exact_d2(qb + qi[u], rb + rj[u], C, nq, nr, qq64[(int64_t)b * nq + qi[u]],
+                                          rr64[(int64_t)b * nr + rj[u]]);
+            }
+        return;
+    }
+    T *tile = reinterpret_cast<T *>(refine_lds);
+    constexpr int kVec = 16 / (int)sizeof(T);
+    for (int c0 = 0; c0 < C; c0 += group) {
+        const int nc = C - c0 < group ? C - c0 : group;
+        __syncthreads();                                        // the previous group has been consumed
+        if (vec_ok) {                                           // rows of nr elements, 16-byte aligned
+            const int64_t vrow = nr / kVec;
+            for (int64_t t = threadIdx.x; t < vrow * nc; t += kRefineThreads) {
+                const int cc = (int)(t / vrow);
+                const int64_t x = t - cc * vrow;
+                *reinterpret_cast<uint4 *>(tile + cc * row + x * kVec) =
+                    *reinterpret_cast<const uint4 *>(rb + (int64_t)(c0 + cc) * nr + x * kVec);
+            }
+        } else {
+            for (int64_t t = threadIdx.x; t < nr * nc; t += kRefineThreads) {
+                const int cc = (int)(t / nr);
+                const int64_t x = t - cc * nr;
+                tile[cc * row + x] = rb[(int64_t)(c0 + cc) * nr + x];
+            }
+        }
+        __syncthreads();
+        for (int cc = 0; cc < nc; ++cc) {
+            float qv[kRefinePer];
+#pragma unroll
+            for (int u = 0; u < kRefinePer; ++u) qv[u] = load_as_float(qb + (int64_t)(c0 + cc) * nq + qi[u]);
+#pragma unroll
+            for (int u = 0; u < kRefinePer; ++u)
+                if (rj[u] >= 0) dot[u] = fma((double)qv[u], (double)load_as_float(tile + cc * row + rj[u]), dot[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kRefinePer; ++u)
+        if (rj[u] >= 0) {
+            const int64_t o = (int64_t)b * total + e0 + threadIdx.x + (int64_t)u * kRefineThreads;
+            dist[o] = (float)((qq64[(int64_t)b * nq + qi[u]] + rr64[(int64_t)b * nr + rj[u]]) - 2.0 * dot[u]);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2508,6 +2627,15 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
                            k, index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount,
                            dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
+    {
+        static unsigned long long configured = 0;       // per instantiation, one bit per device
+        if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_refine_kernel<T>), kRefineLds, &configured))
+            return rc;
+        const int64_t slices = ((int64_t)k * nq + kRefineEntries - 1) / kRefineEntries;
+        hipLaunchKernelGGL((nn_refine_kernel<T>), dim3((unsigned)slices, B), dim3(kRefineThreads), kRefineLds, s, q, r,
+                           q64, r64, C, nq, nr, k, index_base, exact_vec_ok, idx, dist);
+        if (int rc = ispa::check_launch("nn_refine_kernel")) return rc;
+    }
     if (stats) ISPA_HIP(hipMemcpyAsync(stats, count, 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return ISPA_OK;
 }

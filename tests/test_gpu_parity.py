@@ -393,11 +393,9 @@ def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
     for i in range(b):
         want_i, want_d = cnative.nn_exact(q[i].reshape(q.shape[1], -1), r[i].reshape(r.shape[1], -1), k, index_base)
         assert np.array_equal(ind[i], want_i), f"pair {i}: {np.sum(ind[i] != want_i)} index mismatches"
-        scale = (q[i].reshape(q.shape[1], -1).astype(np.float64) ** 2).sum(0)[None, :] + 1.0
         finite = np.isfinite(want_d)
-        # squared distances: 1e-4 relative, plus the rounding floor of the norm expansion
-        floor = 1e-4 if split else 2e-6        # the split filter drops terms up to 3 * 2^-16 |q||r|
-        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]) + floor * np.broadcast_to(scale, want_d.shape)[finite])
+        # squared distances: 1e-4 RELATIVE, no absolute floor (an exact match must come back as 0)
+        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]))
         assert np.all(np.isinf(dist[i][~finite]))
     return st
 
@@ -653,7 +651,7 @@ def test_nn_split_filter(pea):
     perm = torch.stack([torch.randperm(4096, device="cuda", generator=g) for _ in range(16)])
     qq = torch.gather(rr, 2, perm[:, None, :].expand(-1, 128, -1)).contiguous()
     d, i = pea.correspondence.dense_nn(qq, rr, 1, index_base=0, filter="split")
-    assert torch.equal(i[:, 0, :].long(), perm) and float(d.abs().max()) <= 2e-4
+    assert torch.equal(i[:, 0, :].long(), perm) and float(d.abs().max()) == 0.0
     d0, i0 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0)
     d1, i1 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0, filter="split")
     assert torch.equal(i0, i1)
@@ -737,9 +735,9 @@ def test_nn_full_size_properties(pea):
     q = torch.gather(r, 2, perm[:, None, :].expand(-1, 128, -1)).contiguous()   # queries = permuted refs
     dist, ind = pea.correspondence.dense_nn(q, r, 1, index_base=0)
     assert torch.equal(ind[:, 0, :].long(), perm)            # every query finds itself
-    assert float(dist.abs().max()) <= 1e-5
+    assert float(dist.abs().max()) == 0.0                    # ... at distance exactly 0
     d5, i5 = pea.correspondence.dense_nn(q, r, 5, index_base=0)
-    assert torch.equal(i5[:, 0, :].long(), perm)
+    assert torch.equal(i5[:, 0, :].long(), perm) and float(d5[:, 0, :].abs().max()) == 0.0
     assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())       # sorted ascending
 
 
@@ -754,7 +752,7 @@ def test_nn_config5_full_size_properties(pea):
     for dt in (torch.float32, torch.bfloat16):
         d5, i5 = pea.correspondence.dense_nn(q.to(dt), r.to(dt), 5, index_base=0)
         assert torch.equal(i5[:, 0, :].long(), perm)               # every query finds itself first
-        assert float(d5[:, 0, :].abs().max()) <= 1e-5
+        assert float(d5[:, 0, :].abs().max()) == 0.0
         assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())         # sorted ascending
         assert bool((i5 >= 0).all()) and bool((i5 < 128 * 128).all())
         # spot-check three queries of view 1 against the oracle
