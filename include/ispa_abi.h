@@ -157,6 +157,19 @@ int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t 
                  int k, int index_base, float *dist, int32_t *idx, void *workspace,
                  size_t workspace_bytes, int32_t *stats, void *stream);
 
+/* ispa_nn_topk without a workspace argument, for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, results and stream semantics as ispa_nn_topk; the workspace is a static array
+ * of ISPA_NN_NOALLOC_SCRATCH_BYTES inside the library's code object, one copy per GPU, held until the
+ * process ends.  The call allocates and frees nothing.  Problems whose ispa_nn_workspace_bytes_for() exceeds
+ * the array are rejected with ISPA_EWORKSPACE (one 64x64x128 pair needs 4 to 8 MiB, the three 128x128x256 top-5
+ * views of one multi-view query 38 MiB).  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (two streams, two host threads) race; calls on one stream are ordered and safe. */
+#define ISPA_NN_NOALLOC_SCRATCH_BYTES (64u << 20)
+size_t ispa_nn_noalloc_scratch_bytes(void);
+int ispa_nn_topk_noalloc(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
+                         int k, int index_base, float *dist, int32_t *idx, int32_t *stats, void *stream);
+
 /* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
  * next n calls of ispa_nn_topk (its filter kernel, the launch that does the MFMA contraction),
  * ispa_project, ispa_project_prune, ispa_flow_splat, ispa_make_disparity, ispa_zbuffer or

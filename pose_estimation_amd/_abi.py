@@ -40,6 +40,8 @@ SIGNATURES = {
     "ispa_nn_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i]),
     "ispa_nn_workspace_bytes_for": (_sz, [_i, _i, _i, _i64, _i64, _i]),
     "ispa_nn_topk": (_i, [_p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p, _p, _p, _sz, _p, _p]),
+    "ispa_nn_noalloc_scratch_bytes": (_sz, []),
+    "ispa_nn_topk_noalloc": (_i, [_p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p, _p, _p, _p]),
     "ispa_timing_enable": (_i, [_i]),
     "ispa_timing_collect": (_i, [_p, _i, _p]),
     "ispa_l2norm": (_i, [_p, _i, _i, _i64, _p, _p]),

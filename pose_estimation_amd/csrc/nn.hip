@@ -2658,9 +2658,64 @@ extern "C" size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, 
     return a > b ? a : b;
 }
 
+namespace {
+int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr, int k,
+                    int index_base, float *dist, int32_t *idx, void *workspace, size_t workspace_bytes,
+                    int32_t *stats, void *stream, const char *workspace_name);
+
+// Workspace of ispa_nn_topk_noalloc: one array per GPU inside the loaded code object.  In host code the
+// name is only a handle for hipGetSymbolAddress; the device address it yields differs per GPU.
+static __device__ __align__(256) unsigned char scratch[ISPA_NN_NOALLOC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];      // device address of `scratch` per GPU, looked up on first use
+
+int scratch_for_current_device(void **out) {
+    int dev = 0;
+    ISPA_HIP(hipGetDevice(&dev));
+    ISPA_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside [0, %d)", dev, kMaxDevices);
+    void *p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        ISPA_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));    // with device `dev` current: its copy
+        ISPA_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address for the scratch array");
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE); // racing host threads store the same value
+    }
+    *out = p;
+    return ISPA_OK;
+}
+}  // namespace
+
+extern "C" size_t ispa_nn_noalloc_scratch_bytes(void) { return (size_t)ISPA_NN_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int ispa_nn_topk_noalloc(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
+                                    int k, int index_base, float *dist, int32_t *idx, int32_t *stats,
+                                    void *stream) {
+    ISPA_REQUIRE(B >= 0 && nq >= 0, "negative size");
+    if (B == 0 || nq == 0) return ISPA_OK;
+    ISPA_REQUIRE(k >= 1 && k <= kMaxK, "k = %d outside [1, %d]", k, kMaxK);
+    ISPA_REQUIRE(C >= 1 && nr >= 1, "need at least one channel and one reference (C=%d, nr=%lld)", C, (long long)nr);
+    const size_t need = ispa_nn_workspace_bytes_for(dtype, B, C, nq, nr, k);
+    if (need == 0 || need > (size_t)ISPA_NN_NOALLOC_SCRATCH_BYTES)
+        return ispa::fail(ISPA_EWORKSPACE,
+                          "problem too large for ispa_nn_topk_noalloc: it needs %zu bytes of scratch, the static "
+                          "buffer holds %zu (use ispa_nn_topk with a caller workspace)",
+                          need, (size_t)ISPA_NN_NOALLOC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    if (int rc = scratch_for_current_device(&ws)) return rc;
+    return nn_topk_checked(q, r, dtype, B, C, nq, nr, k, index_base, dist, idx, ws,
+                           (size_t)ISPA_NN_NOALLOC_SCRATCH_BYTES, stats, stream, "scratch");
+}
+
 extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,
                             int k, int index_base, float *dist, int32_t *idx, void *workspace,
                             size_t workspace_bytes, int32_t *stats, void *stream) {
+    return nn_topk_checked(q, r, dtype, B, C, nq, nr, k, index_base, dist, idx, workspace, workspace_bytes, stats,
+                           stream, "workspace");
+}
+
+namespace {
+int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr, int k,
+                    int index_base, float *dist, int32_t *idx, void *workspace, size_t workspace_bytes,
+                    int32_t *stats, void *stream, const char *workspace_name) {
     ISPA_REQUIRE(B >= 0 && nq >= 0, "negative size");
     ISPA_REQUIRE(k >= 1 && k <= kMaxK, "k = %d outside [1, %d]", k, kMaxK);
     if (B == 0 || nq == 0) return ISPA_OK;
@@ -2677,8 +2732,8 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
         p.split = false;
     }
     if (workspace_bytes < p.total)
-        return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, p.total);
-    ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "workspace must be 256-byte aligned");
+        return ispa::fail(ISPA_EWORKSPACE, "%s of %zu bytes given, %zu needed", workspace_name, workspace_bytes, p.total);
+    ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "%s must be 256-byte aligned", workspace_name);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ISPA_F32 || dtype == ISPA_F32_SPLIT)
         return run((const float *)q, (const float *)r, B, C, nq, nr, k, index_base, dist, idx, (char *)workspace,
@@ -2686,3 +2741,4 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
     return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, k, index_base, dist, idx,
                (char *)workspace, p, stats, s);
 }
+}  // namespace
