@@ -116,10 +116,12 @@ def measured_traffic(workload_key, kernel, is_default_shape):
 def run_geometry(args, torch, dist, world, rank, dev):
     """Workloads 'project' and 'disparity' (inputs resident in HBM, one GPU's share per rank)."""
     import pose_estimation_amd as pea
-    from pose_estimation_amd import _abi, _device as dv
+    from pose_estimation_amd import _abi, _device as dv, sharding
     n = args.points
     rs = np.random.RandomState(100 + rank)
     pts_np = rs.uniform(-0.4, 0.4, (n, 3))
+    if args.workload == "zbuffer" and not args.unfused:
+        args.morton = True                           # the tiled pass bins chunks of consecutive points per tile
     if args.morton:                                  # one-time model preprocessing, outside the timed region
         pts_np = pts_np[pea.run_proj.spatial_order(pts_np)]
     pts = torch.from_numpy(pts_np).to(dev)
@@ -128,7 +130,12 @@ def run_geometry(args, torch, dist, world, rank, dev):
     if args.workload == "project":
         P = args.poses
         poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
-        poses = np.resize(poses, (P, 4))
+        if world > 1 and P == len(poses):                # config 4: the pose grid sharded over the ranks
+            lo, hi = sharding.shard_range(len(poses), rank, world)
+            poses = poses[lo:hi]
+            P = hi - lo
+        else:
+            poses = np.resize(poses, (P, 4))
         cams = torch.from_numpy(pea.pt2render.camera_matrices(poses)).to(dev)
         depth = torch.full((540, 960), 3.0, dtype=torch.float32, device=dev)
         out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
@@ -169,27 +176,48 @@ def run_geometry(args, torch, dist, world, rank, dev):
         workload = (f"correlation maps at the reference's size: {views} x eccv keypoint maps (K={kpts}) + 1 x acmm "
                     f"dense map for {bsz} pairs of 128x56x56 features per GPU per step")
     elif args.workload == "zbuffer":
-        P = min(args.poses, 720)
+        P = args.poses
         poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
-        poses = np.resize(poses, (P, 4))
+        if world > 1 and P == len(poses):                # config 4: the pose grid sharded over the ranks
+            lo, hi = sharding.shard_range(len(poses), rank, world)
+            poses = poses[lo:hi]
+            P = hi - lo
+        else:
+            poses = np.resize(poses, (P, 4))
         cams = torch.from_numpy(pea.pt2render.camera_matrices(poses)).to(dev)
-        out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
         truth = torch.empty((P, n), dtype=torch.uint8, device=dev)
         packed = torch.empty((P, 540, 960), dtype=torch.int64, device=dev)
+        if args.unfused:
+            out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
 
-        def step():
-            # project -> packed (depth | index) z-buffer -> visibility flags read from the packed keys
-            _abi.check(_abi.lib.ispa_project(pts.data_ptr(), n, cams.data_ptr(), P, out.data_ptr(), st()))
-            _abi.check(_abi.lib.ispa_zbuffer(out.data_ptr(), n, P, 540, 960, 0, packed.data_ptr(), None, None, st()))
-            _abi.check(_abi.lib.ispa_zbuffer_visibility_packed(out.data_ptr(), n, P, packed.data_ptr(), 540, 960,
-                                                               0.01, truth.data_ptr(), st()))
-        units, unit_name, recs = P, "pose-maps/s", 2
-        # project: points read once + 24 B out per point-pose; z-buffer update kernel: 24 B in and one
-        # 8-byte atomic per point-pose (the memset and resolve launches around it are not in its time)
-        alg_bytes = [24.0 * n + 24.0 * n * P, 32.0 * n * P]
-        names = ["project", "zbuffer"]
-        workload = (f"projection + packed atomicMin z-buffer (540x960) + visibility of a {n}-point model at {P} "
-                    f"poses per GPU per step")
+            def step():
+                # project -> packed (depth | index) z-buffer by global atomics -> visibility from the packed keys
+                _abi.check(_abi.lib.ispa_project(pts.data_ptr(), n, cams.data_ptr(), P, out.data_ptr(), st()))
+                _abi.check(_abi.lib.ispa_zbuffer(out.data_ptr(), n, P, 540, 960, 0, packed.data_ptr(), None, None, st()))
+                _abi.check(_abi.lib.ispa_zbuffer_visibility_packed(out.data_ptr(), n, P, packed.data_ptr(), 540, 960,
+                                                                   0.01, truth.data_ptr(), st()))
+            recs = 2
+            # project: points read once + 24 B out per point-pose; z-buffer update kernel: 24 B in and one
+            # 8-byte atomic per point-pose (the memset and resolve launches around it are not in its time)
+            alg_bytes = [24.0 * n + 24.0 * n * P, 32.0 * n * P]
+            names = ["project", "zbuffer"]
+            how = "ispa_project + global-atomic ispa_zbuffer + ispa_zbuffer_visibility_packed"
+        else:
+            need = _abi.lib.ispa_project_zbuffer_workspace_bytes(n, P, 540, 960)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+            def step():
+                _abi.check(_abi.lib.ispa_project_zbuffer(pts.data_ptr(), n, cams.data_ptr(), P, 540, 960, 0, 0.01,
+                                                         packed.data_ptr(), None, None, truth.data_ptr(),
+                                                         ws.data_ptr(), need, st()))
+            recs = 1
+            # the fused pass: the model read once, per pose the key image written once and one flag per point
+            alg_bytes = [24.0 * n + (8.0 * 540 * 960 + 1.0 * n) * P]
+            names = ["zbuffer_tiled"]
+            how = "fused screen-tiled pass (ispa_project_zbuffer): keys in LDS, key image and flags written once"
+        units, unit_name = P, "pose-maps/s"
+        workload = (f"projection + packed (depth|index) z-buffer (540x960) + visibility of a {n}-point model at {P} "
+                    f"poses per GPU per step; {how}")
     else:
         M = args.maps
         params = np.stack([rs.uniform(0, 360, M), rs.uniform(-10, 35, M), np.zeros(M), np.full(M, 3.0)], axis=1)
@@ -276,7 +304,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
                      traffic=measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
                                                  {"project_prune": "project_prune2_kernel",
                                                   "flow_band": "flow_band_kernel", "project": "project2_kernel",
-                                                  "zbuffer": "zbuffer_kernel", "corr_eccv": "corr_eccv_kernel",
+                                                  "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_kernel",
                                                   "corr_acmm_gemm": "corr_acmm_gemm_kernel",
                                                   "make_disparity": "make_disparity_kernel"}[names[dom]],
                                                  args.workload == "corr" or (n == 100000 and (

@@ -132,6 +132,25 @@ int ispa_zbuffer_visibility(const double *pt_render, int64_t n, int n_pose, cons
 int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n, int n_pose, const uint64_t *packed,
                                    int H, int W, double relax, uint8_t *truth, void *stream);
 
+/* Projection + z-buffer + visibility of a point set at n_pose cameras in one pass, screen-tiled: the keys
+ * of a tile of pixels live in LDS, so there are no global atomics and the projected coordinates are never
+ * written (no counterpart in the reference beyond the projection itself, pt2render.py:6-13).
+ * pts (n,3) f64; cams (n_pose,3,4) f64.  Outputs, each optional (NULL to skip), bit-identical to
+ * ispa_project -> ispa_zbuffer -> ispa_zbuffer_visibility_packed:
+ *   packed (n_pose,H,W) u64 keys, winner (n_pose,H,W) int32, depth (n_pose,H,W) f32, truth (n_pose,n) u8.
+ * workspace: ispa_project_zbuffer_workspace_bytes(n, n_pose, H, W) bytes, 256-byte aligned (bounding boxes
+ * of chunks of 256 consecutive points per pose).  Results do not depend on the order of the points; speed
+ * does: with the model's points in a spatially coherent order (e.g. Morton order, once per model) a tile
+ * visits only the chunks that project near it, with points in random order every tile visits every chunk. */
+size_t ispa_project_zbuffer_workspace_bytes(int64_t n, int n_pose, int H, int W);
+int ispa_project_zbuffer(const double *pts, int64_t n, const double *cams, int n_pose, int H, int W,
+                         int radius, double relax, uint64_t *packed, int32_t *winner, float *depth,
+                         uint8_t *truth, void *workspace, size_t workspace_bytes, void *stream);
+/* The same pass over already projected coordinates (pt_render as ispa_project writes it); same workspace size. */
+int ispa_zbuffer_tiled(const double *pt_render, int64_t n, int n_pose, int H, int W, int radius, double relax,
+                       uint64_t *packed, int32_t *winner, float *depth, uint8_t *truth, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense nearest-neighbour correspondence
  * ---------------------------------------------------------------------------------------- */

@@ -37,6 +37,9 @@ SIGNATURES = {
     "ispa_zbuffer": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "ispa_zbuffer_visibility": (_i, [_p, _i64, _i, _p, _i, _i, _d, _p, _p]),
     "ispa_zbuffer_visibility_packed": (_i, [_p, _i64, _i, _p, _i, _i, _d, _p, _p]),
+    "ispa_project_zbuffer_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "ispa_project_zbuffer": (_i, [_p, _i64, _p, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _sz, _p]),
+    "ispa_zbuffer_tiled": (_i, [_p, _i64, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _sz, _p]),
     "ispa_nn_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i]),
     "ispa_nn_workspace_bytes_for": (_sz, [_i, _i, _i, _i64, _i64, _i]),
     "ispa_nn_topk": (_i, [_p, _p, _i, _i, _i, _i64, _i64, _i, _i, _p, _p, _p, _sz, _p, _p]),

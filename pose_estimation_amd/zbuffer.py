@@ -27,6 +27,63 @@ def zbuffer(pt_render, size=(540, 960), radius=0, want=("winner", "depth")):
     return {k: dv.back(v, as_tensor) for k, v in out.items()}
 
 
+def project_zbuffer(model_pts, cams, size=(540, 960), radius=0, relax=0.0, want=("packed", "truth"), pt_render=None):
+    """Projection + z-buffer + visibility in one screen-tiled pass (ispa_project_zbuffer).
+
+    model_pts (N,3), cams (3,4) or (n_pose,3,4); or pt_render=(n_pose,3,N) already projected coordinates
+    (ispa_zbuffer_tiled).  `want` picks the outputs: 'packed' u64 keys (as int64), 'winner' int32 (-1 empty),
+    'depth' float32 (+inf empty), each (n_pose,H,W); 'truth' (n_pose,N) bool = takes part and lies within
+    `relax` behind the nearest point of its pixel.  Same values as zbuffer() + visibility() on
+    get_render_location's output.  Put the model's points in run_proj.spatial_order first: results are the
+    same for any order, but a tile only skips the chunks of points that project elsewhere when consecutive
+    points are neighbours in space."""
+    from_render = pt_render is not None
+    src_in = pt_render if from_render else model_pts
+    as_tensor = dv.is_tensor(src_in)
+    src = dv.to_dev(src_in, torch.float64)
+    if from_render:
+        single = src.dim() == 2
+        if single:
+            src = src[None]
+        n_pose, _, n = src.shape
+        cams_t = None
+    else:
+        cams_t = dv.to_dev(cams, torch.float64)
+        single = cams_t.dim() == 2
+        cams_t = cams_t.reshape(-1, 3, 4)
+        n_pose, n = cams_t.shape[0], src.shape[0]
+        if src.dim() != 2 or src.shape[1] != 3:
+            raise ValueError("model_pts must be (N,3)")
+    h, w = int(size[0]), int(size[1])
+    unknown = set(want) - {"packed", "winner", "depth", "truth"}
+    if unknown or not want:
+        raise ValueError(f"want must name some of packed / winner / depth / truth (got {sorted(unknown)})")
+    packed = dv.empty((n_pose, h, w), torch.int64) if "packed" in want else None
+    winner = dv.empty((n_pose, h, w), torch.int32) if "winner" in want else None
+    depth = dv.empty((n_pose, h, w), torch.float32) if "depth" in want else None
+    truth = dv.empty((n_pose, n), torch.uint8) if "truth" in want else None
+    need = _abi.lib.ispa_project_zbuffer_workspace_bytes(n, n_pose, h, w)
+    ws = dv.empty((need,), torch.uint8)
+    if from_render:
+        _abi.check(_abi.lib.ispa_zbuffer_tiled(dv.ptr(src), n, n_pose, h, w, int(radius), float(relax), dv.ptr(packed),
+                                               dv.ptr(winner), dv.ptr(depth), dv.ptr(truth), dv.ptr(ws), need,
+                                               dv.stream_ptr()))
+    else:
+        _abi.check(_abi.lib.ispa_project_zbuffer(dv.ptr(src), n, dv.ptr(cams_t), n_pose, h, w, int(radius), float(relax),
+                                                 dv.ptr(packed), dv.ptr(winner), dv.ptr(depth), dv.ptr(truth),
+                                                 dv.ptr(ws), need, dv.stream_ptr()))
+    out = {"packed": packed, "winner": winner, "depth": depth, "truth": None if truth is None else truth.bool()}
+    out = {k: (v[0] if single else v) for k, v in out.items() if v is not None}
+    return {k: dv.back(v, as_tensor) for k, v in out.items()}
+
+
+def _check_images(d, n_pose):
+    """The kernels index image p of a (n_pose,H,W) stack for pose p: anything else would read out of bounds."""
+    if d.dim() != 3 or d.shape[0] != n_pose:
+        raise ValueError(f"need one (H,W) image per pose: pt_render has {n_pose} pose(s), the image stack has shape "
+                         f"{tuple(d.shape)}")
+
+
 def visibility(pt_render, depth, relax=0.0):
     """visible = lands in the image with finite positive z, and z - depth[y,x] <= relax.
 
@@ -41,6 +98,7 @@ def visibility(pt_render, depth, relax=0.0):
         if single:
             pr, d = pr[None], d[None]
         n_pose, _, n = pr.shape
+        _check_images(d, n_pose)
         h, w = d.shape[-2:]
         truth = dv.empty((n_pose, n), torch.uint8)
         _abi.check(_abi.lib.ispa_zbuffer_visibility_packed(dv.ptr(pr), n, n_pose, dv.ptr(d), h, w, float(relax),
@@ -52,6 +110,7 @@ def visibility(pt_render, depth, relax=0.0):
     if single:
         pr, d = pr[None], d[None]
     n_pose, _, n = pr.shape
+    _check_images(d, n_pose)
     h, w = d.shape[-2:]
     truth = dv.empty((n_pose, n), torch.uint8)
     _abi.check(_abi.lib.ispa_zbuffer_visibility(dv.ptr(pr), n, n_pose, dv.ptr(d), h, w, float(relax),

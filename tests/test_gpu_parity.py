@@ -375,6 +375,90 @@ def test_zbuffer(pea, golden_geometry):
     assert np.array_equal(got["winner"][1], ozb.zbuffer(rr[1], 540, 960)[1])
 
 
+def _zb_oracle(pts, cam, h, w, radius, relax):
+    render = cnative.project_fma(pts, cam)
+    with np.errstate(invalid="ignore", over="ignore"):
+        key, win, depth = ozb.zbuffer(render, h, w, radius=radius)
+        vis = ozb.zbuffer_visibility(render, depth, relax=relax)
+    return render, key, win, depth, vis
+
+
+def test_project_zbuffer_tiled_against_oracle(pea):
+    """Screen-tiled fused pass (projection + z-buffer + visibility): keys, winners, depths and flags
+    bit-exact against the oracle for points in random order (every tile visits every chunk) and in Morton
+    order (chunks culled per tile), several image sizes (odd width: scalar stores), splat radii, and
+    points that cannot take part (NaN, inf, behind the camera, off screen)."""
+    rs = np.random.RandomState(61)
+    pts = rs.uniform(-0.45, 0.45, (7000, 3))
+    pts[::97] *= 3.0                                   # some far off screen
+    pts[5] = [np.nan, 0.1, 0.1]
+    pts[6] = [np.inf, 0.1, 0.1]
+    pts[7] = [0.0, 1e300, 0.0]
+    poses = np.array([[30.0, 10.0, 0.0, 3.0], [200.0, -5.0, 12.0, 1.1], [95.0, 35.0, -8.0, 0.3]])   # last: camera inside the cloud
+    cams = pea.pt2render.camera_matrices(poses)
+    order = pea.run_proj.spatial_order(np.nan_to_num(pts, nan=0.0, posinf=1.0, neginf=-1.0))
+    for (h, w), radius in (((540, 960), 0), ((540, 960), 2), ((131, 77), 1), ((64, 128), 0)):
+        cam_set = cams.copy()
+        if (h, w) != (540, 960):                       # move the principal point into the small image
+            cam_set[:, 0] += cam_set[:, 2] * (w / 2 - 480)
+            cam_set[:, 1] += cam_set[:, 2] * (h / 2 - 270)
+        for arr in (pts, pts[order]):
+            got = pea.zbuffer.project_zbuffer(arr, cam_set, (h, w), radius=radius, relax=0.01,
+                                              want=("packed", "winner", "depth", "truth"))
+            for p in range(len(poses)):
+                render, key, win, depth, vis = _zb_oracle(arr, cam_set[p], h, w, radius, 0.01)
+                assert np.array_equal(got["packed"][p].view(np.uint64), key), (h, w, radius, p)
+                assert np.array_equal(got["winner"][p], win) and np.array_equal(got["depth"][p], depth)
+                assert np.array_equal(got["truth"][p], vis)
+            assert got["truth"].sum() > 100
+    # flags only, one camera, no images written
+    only = pea.zbuffer.project_zbuffer(pts, cams[0], want=("truth",))
+    assert set(only) == {"truth"} and np.array_equal(only["truth"], _zb_oracle(pts, cams[0], 540, 960, 0, 0.0)[4])
+    # the same pass over projected coordinates
+    render = pea.pt2render.get_render_location(pts, cams)
+    got = pea.zbuffer.project_zbuffer(None, None, radius=2, relax=0.01, want=("packed", "truth"), pt_render=render)
+    for p in range(len(poses)):
+        _, key, _, _, vis = _zb_oracle(pts, cams[p], 540, 960, 2, 0.01)
+        assert np.array_equal(got["packed"][p].view(np.uint64), key) and np.array_equal(got["truth"][p], vis)
+    # empty point set: every pixel empty
+    got = pea.zbuffer.project_zbuffer(np.zeros((0, 3)), cams[:2], (33, 40), want=("winner", "depth", "truth"))
+    assert (got["winner"] == -1).all() and np.isinf(got["depth"]).all() and got["truth"].shape == (2, 0)
+
+
+def test_zbuffer_config4_pose_sweep(pea):
+    """100k points x 36 distinct poses: ispa_project -> ispa_zbuffer -> visibility (global atomics) and the
+    fused tiled pass must agree bit for bit on every pose; 3 poses against the oracle; a re-run of both gives
+    the same bits (atomics commute: the result does not depend on scheduling)."""
+    import torch
+    rs = np.random.RandomState(44)
+    pts = rs.uniform(-0.4, 0.4, (100000, 3))
+    pts = pts[pea.run_proj.spatial_order(pts)]
+    poses = np.array([[az, el, 0.0, 3.0] for az in range(0, 360, 30) for el in (-10.0, 10.0, 35.0)])
+    cams = pea.pt2render.camera_matrices(poses)
+    pts_d = torch.from_numpy(pts).cuda()
+    cams_d = torch.from_numpy(cams).cuda()
+
+    def unfused():
+        render = pea.pt2render.get_render_location(pts_d, cams_d)
+        zb = pea.zbuffer.zbuffer(render, (540, 960), want=())
+        return zb["packed"], pea.zbuffer.visibility(render, zb["packed"], relax=0.01)
+
+    def fused():
+        out = pea.zbuffer.project_zbuffer(pts_d, cams_d, (540, 960), relax=0.01)
+        return out["packed"], out["truth"]
+    pa, ta = unfused()
+    pb, tb = fused()
+    assert torch.equal(pa, pb) and torch.equal(ta, tb)
+    pa2, ta2 = unfused()
+    pb2, tb2 = fused()
+    assert torch.equal(pa, pa2) and torch.equal(ta, ta2) and torch.equal(pb, pb2) and torch.equal(tb, tb2)
+    for p in (0, 17, 35):
+        _, key, _, _, vis = _zb_oracle(pts, cams[p], 540, 960, 0, 0.01)
+        assert np.array_equal(pb[p].cpu().numpy().view(np.uint64), key)
+        assert np.array_equal(tb[p].cpu().numpy(), vis)
+        assert 20000 < int(vis.sum()) < 100000
+
+
 # ---------------------------------------------------------------- dense nearest neighbour
 def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
     import torch
