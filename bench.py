@@ -53,9 +53,9 @@ def parse():
     ap.add_argument("--matches", action="store_true",
                     help="nn: queries are noisy copies of (permuted) template cells, as for two views of one object: "
                          "every nearest distance is small, so every returned distance takes the float64 refinement")
-    ap.add_argument("--morton", action="store_true",
-                    help="geometry workloads: put the model points in Morton order first (run_proj.spatial_order), "
-                         "so that neighbouring lanes hit neighbouring pixels")
+    ap.add_argument("--sorted", "--morton", dest="morton", action="store_true",
+                    help="geometry workloads: put the model points in space-filling-curve order first "
+                         "(run_proj.spatial_order, once per model), so that neighbouring lanes hit neighbouring pixels")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' with ranks sharing one GPU rehearses the multi-rank "
                          "code path on a single-GPU box (not a measurement)")
@@ -299,7 +299,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.workload == "corr" else "f64", "data": "synthetic",
-        "config": {"workload": workload, "points": n, "point_order": "morton" if args.morton else "as generated"},
+        "config": {"workload": workload, "points": n, "point_order": "hilbert curve (run_proj.spatial_order)" if args.morton else "as generated"},
         "roofline": dict(roof,
                      traffic=measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
                                                  {"project_prune": "project_prune2_kernel",

@@ -20,13 +20,23 @@
 namespace {
 
 constexpr int kChunk = 64;                  // points per chunk: a wave takes a chunk visit
-constexpr int kZThreads = 512;              // two workgroups per CU
+#ifndef ZB_THREADS
+#define ZB_THREADS 512
+#define ZB_TILE_H 64
+#define ZB_CACHE 94
+#define ZB_WG_PER_CU 2
+#endif
+constexpr int kZThreads = ZB_THREADS;       // two workgroups per CU
+constexpr int kWgPerCu = ZB_WG_PER_CU;
 constexpr int kZWaves = kZThreads / 64;
-constexpr int kBatch = 4;                   // chunk visits whose loads a wave has in flight together
-constexpr int kTileW = 128, kTileH = 64;    // 8192 keys = 64 KiB of LDS
+#ifndef ZB_BATCH
+#define ZB_BATCH 4
+#endif
+constexpr int kBatch = ZB_BATCH;                   // chunk visits whose loads a wave has in flight together
+constexpr int kTileW = 128, kTileH = ZB_TILE_H;   // 8192 keys = 64 KiB of LDS
 constexpr int kListMax = 2 * kZThreads;     // visiting chunks listed at a time (4 KiB)
 constexpr int kRounds = 4;                  // rounds of kZThreads boxes a list segment tries to take
-constexpr int kCacheVisits = 94;            // chunk visits whose tile offsets pass 1 leaves in LDS for pass 2 (12 KiB)
+constexpr int kCacheVisits = ZB_CACHE;            // chunk visits whose tile offsets pass 1 leaves in LDS for pass 2 (12 KiB)
 constexpr int kGroup = 4;                   // consecutive items taken off the counter at a time
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr int kBoxWhole = 32000;            // |bound| of a box that covers every image (H, W <= 16384)
@@ -309,7 +319,7 @@ __device__ unsigned long long zb_stamps[16];
 // Persistent workgroups: each takes (pose, tile) items off a counter until none is left, so that no CU waits
 // for a workgroup launch between two tiles and two resident workgroups overlap each other's phases.
 template <bool FROM_RENDER>
-__global__ __launch_bounds__(kZThreads, 2 * kZThreads / 256) void zb_tile_kernel(
+__global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile_kernel(
     const double *__restrict__ src, int64_t n, const double *__restrict__ cams, int n_pose, int H, int W, int radius,
     double relax, const short4 *__restrict__ box, const int4 *__restrict__ pose_box, int nchunks, int tiles_x,
     int tiles_y, int *__restrict__ counter, unsigned long long *__restrict__ packed, int32_t *__restrict__ winner,
@@ -500,7 +510,7 @@ int zb_launch(const double *src, int64_t n, const double *cams, int n_pose, int 
     int dev = 0, cus = 0;
     ISPA_HIP(hipGetDevice(&dev));
     ISPA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t resident = (int64_t)cus * 2;                                     // two workgroups per CU (LDS)
+    const int64_t resident = (int64_t)cus * kWgPerCu;                                     // two workgroups per CU (LDS)
     const unsigned grid = (unsigned)(items < resident ? items : resident);
     const ispa::TimingSlot timed = ispa::timing_begin(s);
     hipLaunchKernelGGL(zb_tile_kernel<FROM_RENDER>, dim3(grid), dim3(kZThreads), 0, s, src, n, cams, n_pose, H, W, radius,

@@ -102,26 +102,62 @@ def project_prune(model_pts, cams, depth_maps, crop_params=None, variant="A", er
     return tuple(res)
 
 
-def spatial_order(points, bits=10):
-    """Permutation that puts a point set in Morton (Z-curve) order of its bounding box.
+def spatial_order(points, bits=10, curve="hilbert"):
+    """Permutation that puts a point set in the order of a space-filling curve through its bounding box
+    (`curve` = "hilbert", or "morton" for the Z-curve).
 
     Optional one-time preprocessing of a model's surface samples (the reference draws them in random
     order, run_proj.py:15-22): points that are neighbours in space become neighbours in the array, so
-    the lanes of a wave project onto neighbouring pixels and the depth gathers, LDS and z-buffer
-    atomics of the kernels coalesce (measured: z-buffer -21 %, make_disparity -13 %, project_prune
-    -7 % on a uniform random cloud).  Per-point outputs come back in the order given, so results for
-    `points[perm]` are the results for `points` permuted the same way; only "last writer wins" splats
-    (make_disparity) depend on the order itself, as they do in the reference."""
+    the lanes of a wave project onto neighbouring pixels, the depth gathers and LDS atomics of the kernels
+    coalesce, and the tiled z-buffer pass (zbuffer.project_zbuffer) can skip, per screen tile, the chunks
+    of consecutive points that project elsewhere.  The Hilbert curve has no jumps, so a run of consecutive
+    points is a more compact blob than on the Z-curve.  Per-point outputs come back in the order given, so
+    results for `points[perm]` are the results for `points` permuted the same way; only "last writer wins"
+    splats (make_disparity) depend on the order itself, as they do in the reference."""
     p = np.asarray(points, dtype=np.float64)
     if p.ndim != 2 or p.shape[1] != 3:
         raise ValueError("points must be (N,3)")
+    if curve not in ("hilbert", "morton"):
+        raise ValueError("curve must be 'hilbert' or 'morton'")
     if len(p) == 0:
         return np.zeros(0, dtype=np.int64)
     lo, hi = p.min(0), p.max(0)
     scale = (2 ** bits - 1) / np.where(hi > lo, hi - lo, 1.0)
     g = np.clip(((p - lo) * scale).astype(np.int64), 0, 2 ** bits - 1)
+    if curve == "hilbert":
+        g = _hilbert_transpose(g, bits)
     code = np.zeros(len(p), dtype=np.int64)
-    for b in range(bits):                            # interleave x, y, z bits
+    for b in range(bits):                            # interleave the bits of the three axes
         for axis in range(3):
-            code |= ((g[:, axis] >> b) & 1) << (3 * b + axis)
+            # Hilbert: axis 0 carries the most significant bit of each triple
+            shift = 3 * b + (2 - axis if curve == "hilbert" else axis)
+            code |= ((g[:, axis] >> b) & 1) << shift
     return np.argsort(code, kind="stable")
+
+
+def _hilbert_transpose(grid, bits):
+    """Skilling's axes-to-transpose transform (AIP Conf. Proc. 707, 2004), vectorised over points: integer
+    grid coordinates (N,3) -> the 'transposed' Hilbert index, whose bit-interleaving is the curve position."""
+    x = grid.copy()
+    q = 1 << (bits - 1)
+    while q > 1:                                     # inverse undo of the excess work
+        mask = q - 1
+        for i in range(3):
+            flip = (x[:, i] & q) != 0
+            x[flip, 0] ^= mask                       # invert the low bits of axis 0
+            t = (x[:, 0] ^ x[:, i]) & mask           # else exchange the low bits of axis 0 and axis i
+            t[flip] = 0
+            x[:, 0] ^= t
+            x[:, i] ^= t
+        q >>= 1
+    for i in range(1, 3):                            # Gray encode
+        x[:, i] ^= x[:, i - 1]
+    t = np.zeros(len(x), dtype=np.int64)
+    q = 1 << (bits - 1)
+    while q > 1:
+        sel = (x[:, 2] & q) != 0
+        t[sel] ^= q - 1
+        q >>= 1
+    for i in range(3):
+        x[:, i] ^= t
+    return x

@@ -78,10 +78,16 @@ def test_spatial_order_host_logic():
     from pose_estimation_amd import run_proj
     rs = np.random.RandomState(5)
     pts = rs.uniform(-1, 1, (5000, 3))
-    perm = run_proj.spatial_order(pts)
-    assert perm.dtype == np.int64 and sorted(perm.tolist()) == list(range(5000))
     step = lambda p: np.linalg.norm(np.diff(p, axis=0), axis=1).mean()
-    assert step(pts[perm]) < 0.25 * step(pts)                # neighbours in the array are neighbours in space
+    for curve in ("hilbert", "morton"):
+        perm = run_proj.spatial_order(pts, curve=curve)
+        assert perm.dtype == np.int64 and sorted(perm.tolist()) == list(range(5000))
+        assert step(pts[perm]) < 0.25 * step(pts)            # neighbours in the array are neighbours in space
+    # the Hilbert curve visits a full grid in unit steps (no jumps, unlike the Z-curve)
+    grid = np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(float)
+    walk = grid[run_proj.spatial_order(grid, bits=3, curve="hilbert")]
+    assert (np.abs(np.diff(walk, axis=0)).sum(1) == 1).all()
+    perm = run_proj.spatial_order(pts)
     assert np.array_equal(run_proj.spatial_order(pts), perm)  # deterministic
     flat = pts.copy()
     flat[:, 2] = 0.5                                          # a degenerate axis must not divide by zero
