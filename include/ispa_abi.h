@@ -40,6 +40,11 @@ typedef enum ispa_status {
 enum { ISPA_VIS_A = 0, ISPA_VIS_B = 1 };          /* depth-visibility variants         */
 /* feature dtypes for ispa_nn_topk; ISPA_F32_SPLIT = float32 inputs, split-bfloat16 MFMA filter */
 enum { ISPA_F32 = 0, ISPA_BF16 = 1, ISPA_F32_SPLIT = 2 };
+/* OR'ed into the dtype of ispa_nn_topk (float32 features only): L2NormLayer.forward
+ * (ucn_code/lib/layers/l2norm_layer.py:18-29) is applied to both maps inside the norms pass, i.e. the call
+ * returns what ispa_l2norm on q and r followed by ispa_nn_topk returns, bit for bit; the normalised copies
+ * live in the workspace (ask ispa_nn_workspace_bytes_for with the flag set). */
+enum { ISPA_NN_NORMALIZE = 256 };
 
 int ispa_abi_version(void);
 const char *ispa_last_error(void);
@@ -216,23 +221,25 @@ int ispa_resize_bilinear(const float *in, int B, int C, int H, int W, int oh, in
 /* eccv_net.CorrelationMapLayer.forward(feature1, feature2, knn_inds)
  *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:181-231
  * f1 (real), f2 (template): (B,C,H,W) f32; knn (K,2) int64 [x,y] on the grid x grid lattice.
- * out (B,K,grid,grid) f32 = relu(corr) / sum_yx exp(relu(corr)) * 10.
- * workspace: 2*B*C*grid*grid floats (the resized maps); not used and may be NULL when H == W == grid. */
+ * out (B,K,grid,grid) f32 = relu(corr) / sum_yx exp(relu(corr)) * 10.  The 56 -> 28 bilinear resize
+ * (eccv_net.py:184-185) happens inside the kernels' loaders: no resized copy is made.  A keypoint off the
+ * lattice correlates as an all-zero template (the reference raises IndexError; so does the Python layer).
+ * workspace: unused, may be NULL (kept in the signature for ABI version 1). */
 int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_t *knn, int B, int C, int H,
                        int W, int K, int grid, float *out, float *workspace, void *stream);
 
 /* The per-view loop of eccv_net.Net.forward around that layer, in one call
  *   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:282-289 (loop, stack, permute)
  * f1, f2 (B,V,C,H,W) f32; knn (V,K,2) int64, one keypoint list per view; out (B,V,K,grid,grid) f32,
- * which is the reference's `embedding` before its .view().  workspace: 2*B*V*C*grid*grid floats (may be NULL when
- * H == W == grid). */
+ * which is the reference's `embedding` before its .view().  workspace: unused, may be NULL. */
 int ispa_corr_map_eccv_views(const float *f1, const float *f2, const int64_t *knn, int B, int V, int C, int H,
                              int W, int K, int grid, float *out, float *workspace, void *stream);
 
 /* acmm_net CorrelationMapLayer.forward, correlation part
  *   classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
  * mask (B,1,H,W) f32 (max-pooled 2x2 ceil inside).  out (B, grid*grid, grid, grid) f32.
- * workspace: 2*B*C*cells + 2*B*ceil(cells/128)*cells floats, cells = grid*grid. */
+ * workspace: 2*B*C*cells + 2*B*ceil(cells/128)*cells floats, cells = grid*grid (both maps at the grid's
+ * size, written by one launch, and the column partials of the normalisation). */
 int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
                        int W, int grid, float *out, float *workspace, void *stream);
 

@@ -27,7 +27,7 @@ def _workspace(nbytes):
     return ws
 
 
-def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native", num_query=None):
+def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native", num_query=None, normalize=False):
     """k nearest reference cells (squared L2) for every query column.
 
     query (B,C,Hq,Wq) or (B,C,n); ref (B,C,H,W) or (B,C,nr); float32, or bfloat16 torch tensors.
@@ -37,6 +37,10 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
 
     filter="split" (float32 inputs, k=1): the filter pass contracts a bfloat16 hi/lo split of the
     inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones.
+
+    normalize=True (float32 inputs): both maps pass through L2NormLayer.forward (l2norm_layer.py:18-29)
+    inside the call, as the reference's net does in front of the KNN layer (train.prototxt:2096-2115); the
+    result is that of dense_nn(l2norm(query), l2norm(ref), ...), bit for bit, without the extra passes.
 
     num_query (B,) or (B,1): the layer's `num_coord` bottom with `use_all_query: false`
     (train.prototxt:2128-2141) - only the first num_query[b] query columns of item b are real; the
@@ -60,6 +64,10 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     ind = dv.empty((b, k, nq), torch.int32)
     stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
     code = _abi.BF16 if bf16 else (_abi.F32_SPLIT if filter == "split" else _abi.F32)
+    if normalize:
+        if bf16:
+            raise ValueError("normalize=True takes float32 features")
+        code |= _abi.NN_NORMALIZE
     key = (code, b, c, nq, nr, k)
     need = _ws_bytes.get(key)
     if need is None:
@@ -175,9 +183,8 @@ class CorrelationMapLayer:
         b, c, h, w = f1.shape
         k = knn.shape[0]
         out = dv.empty((b, k, self.grid, self.grid), torch.float32)
-        ws = None if (h, w) == (self.grid, self.grid) else _workspace(2 * b * c * self.grid * self.grid * 4)
         _abi.check(_abi.lib.ispa_corr_map_eccv(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, c, h, w, k, self.grid,
-                                               dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
+                                               dv.ptr(out), None, dv.stream_ptr()))
         return dv.back(out, as_tensor)
 
     __call__ = forward
@@ -205,9 +212,8 @@ class CorrelationMapLayer:
             raise ValueError("knn_inds must be (V,K,2)")
         k = knn.shape[1]
         out = dv.empty((b, v, k, self.grid, self.grid), torch.float32)
-        ws = None if (h, w) == (self.grid, self.grid) else _workspace(2 * b * v * c * self.grid * self.grid * 4)
         _abi.check(_abi.lib.ispa_corr_map_eccv_views(dv.ptr(f1), dv.ptr(f2), dv.ptr(knn), b, v, c, h, w, k, self.grid,
-                                                     dv.ptr(out), dv.ptr(ws), dv.stream_ptr()))
+                                                     dv.ptr(out), None, dv.stream_ptr()))
         return dv.back(out, as_tensor)
 
 

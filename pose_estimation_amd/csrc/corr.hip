@@ -10,6 +10,47 @@
 
 namespace {
 
+// torch.nn.UpsamplingBilinear2d (align_corners=True) read straight from the source map: the value of cell
+// (y, x) of the (oh, ow) grid.  Source coordinate, lower index by truncation, weights (1-l, l), rows combined
+// after columns: all in float, the operation order of resize_bilinear_kernel (same bits).  A map already at
+// the grid's size has scale 1: weights exactly 1 and 0.
+struct Resample {
+    int H, W;
+    float sy, sx;
+};
+__host__ __device__ inline Resample make_resample(int H, int W, int oh, int ow) {
+    Resample r;
+    r.H = H;
+    r.W = W;
+    r.sy = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f;
+    r.sx = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
+    return r;
+}
+struct Taps {                 // the four source offsets and the weights of one grid cell
+    int o00, o01, o10, o11;
+    float hx, lx, hy, ly;
+};
+__device__ __forceinline__ Taps make_taps(const Resample &r, int y, int x) {
+    const float fy = r.sy * (float)y, fx = r.sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, r.H - 1), x1 = min(x0 + 1, r.W - 1);
+    Taps t;
+    t.ly = fy - (float)y0;
+    t.lx = fx - (float)x0;
+    t.hy = 1.f - t.ly;
+    t.hx = 1.f - t.lx;
+    t.o00 = y0 * r.W + x0;
+    t.o01 = y0 * r.W + x1;
+    t.o10 = y1 * r.W + x0;
+    t.o11 = y1 * r.W + x1;
+    return t;
+}
+__device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps &t) {
+    const float top = plane[t.o00] * t.hx + plane[t.o01] * t.lx;
+    const float bot = plane[t.o10] * t.hx + plane[t.o11] * t.lx;
+    return t.hy * top + t.ly * bot;
+}
+
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ in, int64_t planes,
                                                               int H, int W, int oh, int ow, float sy, float sx,
                                                               float *__restrict__ out) {
@@ -31,6 +72,21 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__res
     out[t] = hy * top + ly * bot;
 }
 
+// Both feature maps of a correlation call to the grid's size in one launch (eccv_net.py:184-185 /
+// net_final_old.py:33-34): thread = one grid cell of one (item, channel) plane of either map.
+__global__ __launch_bounds__(256) void resample2_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
+                                                        int64_t planes, int grid, Resample rs,
+                                                        float *__restrict__ out1, float *__restrict__ out2) {
+    const int cells = grid * grid;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= planes * cells) return;
+    const int cell = (int)(t % cells);
+    const int64_t p = t / cells;
+    const Taps tp = make_taps(rs, cell / grid, cell % grid);
+    const float *src = (blockIdx.y ? in2 : in1) + p * rs.H * rs.W;
+    (blockIdx.y ? out2 : out1)[t] = sample(src, tp);
+}
+
 __device__ __forceinline__ float block_sum(float v, float *scratch) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
@@ -41,20 +97,24 @@ __device__ __forceinline__ float block_sum(float v, float *scratch) {
     return s;
 }
 
-// one block per (b, k): out[b][k][:] = relu(t . f1[:, p]) / sum_p exp(...) * 10
-// (item b of a (B, views, ...) batch uses the keypoint list of view b % views)
-__global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict__ f1r, const float *__restrict__ f2r,
+// one block per (b, k): out[b][k][:] = relu(t . f1[:, p]) / sum_p exp(...) * 10, the maps resampled to the
+// grid while they are read (item b of a (B, views, ...) batch uses the keypoint list of view b % views;
+// a keypoint off the grid gives a template of zeros: the Python layer raises IndexError before it gets here)
+__global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
                                                         const int64_t *__restrict__ knn, int views, int C, int grid,
-                                                        int K, float *__restrict__ out) {
+                                                        Resample rs, int K, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tmpl = sm;            // C floats
     float *scratch = sm + C;     // 4 floats
     const int k = blockIdx.x, b = blockIdx.y;
     const int cells = grid * grid;
+    const int64_t plane = (int64_t)rs.H * rs.W;
     const int64_t *kn = knn + (int64_t)(b % views) * K * 2;
-    const int kx = (int)kn[2 * k], ky = (int)kn[2 * k + 1];
-    const int64_t base = (int64_t)b * C * cells;
-    for (int c = threadIdx.x; c < C; c += 256) tmpl[c] = f2r[base + (int64_t)c * cells + ky * grid + kx];
+    const int64_t kx = kn[2 * k], ky = kn[2 * k + 1];
+    const bool on_grid = kx >= 0 && kx < grid && ky >= 0 && ky < grid;
+    const int64_t base = (int64_t)b * C * plane;
+    const Taps tk = make_taps(rs, on_grid ? (int)ky : 0, on_grid ? (int)kx : 0);
+    for (int c = threadIdx.x; c < C; c += 256) tmpl[c] = on_grid ? sample(f2 + base + (int64_t)c * plane, tk) : 0.f;
     __syncthreads();
     // pass 1: relu(correlation) to the output, sum of exp; pass 2: every thread rescales the
     // cells it wrote itself
@@ -62,16 +122,17 @@ __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict_
     float esum = 0.f;
     for (int p = threadIdx.x; p < cells; p += 256) {
         float acc = 0.f;
-        const float *col = f1r + base + p;
+        const Taps tp = make_taps(rs, p / grid, p % grid);
+        const float *col = f1 + base;
         int c = 0;
-        for (; c + 8 <= C; c += 8) {                 // 8 loads in flight, then the ordered chain
+        for (; c + 8 <= C; c += 8) {                 // 8 cells' loads in flight, then the ordered chain
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * cells];
+            for (int u = 0; u < 8; ++u) v[u] = sample(col + (int64_t)(c + u) * plane, tp);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = fmaf(tmpl[c + u], v[u], acc);
         }
-        for (; c < C; ++c) acc = fmaf(tmpl[c], col[(int64_t)c * cells], acc);
+        for (; c < C; ++c) acc = fmaf(tmpl[c], sample(col + (int64_t)c * plane, tp), acc);
         acc = fmaxf(acc, 0.f);
         o[p] = acc;
         esum += expf(acc);
@@ -80,34 +141,42 @@ __global__ __launch_bounds__(256) void corr_eccv_kernel(const float *__restrict_
     for (int p = threadIdx.x; p < cells; p += 256) o[p] = o[p] / denom * 10.f;
 }
 
-// Large grids (a 128 x 128 map is 16 MB per item): corr_eccv_kernel would stream the whole first map
-// once per keypoint through a single CU.  Here one block owns 256 cells and all K <= 16 keypoints, so the
-// map is read once, by many CUs; the per-(b, k) normalisation runs afterwards (corr_eccv_scale_kernel)
-// with the same summation order as corr_eccv_kernel, and the dot products are the same fmaf chains,
-// so both paths give the same bits.
+// Up to 16 keypoints: corr_eccv_kernel would resample and stream the whole first map once per keypoint.
+// Here a block owns 64 cells and all K <= 16 keypoints, so the map is read (and resampled) once, by many
+// CUs; its four waves each take a quarter of the channels (a cell's correlation is then the sum of four
+// partial fmaf chains, added in wave order: deterministic, last-bit different from corr_eccv_kernel's
+// single chain); the per-(b, k) normalisation runs afterwards (corr_eccv_scale_kernel).
 constexpr int kEccvMaxK = 16;
-__global__ __launch_bounds__(256) void corr_eccv_tile_kernel(const float *__restrict__ f1r,
-                                                             const float *__restrict__ f2r,
+constexpr int kEccvCells = 64;
+__global__ __launch_bounds__(256) void corr_eccv_tile_kernel(const float *__restrict__ f1,
+                                                             const float *__restrict__ f2,
                                                              const int64_t *__restrict__ knn, int views, int C,
-                                                             int grid, int K, float *__restrict__ out) {
+                                                             int grid, Resample rs, int K, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];           // tm[c][16]: keypoint kk's channel c
+    __shared__ float red[3][kEccvMaxK][kEccvCells];                      // partial sums of waves 1..3
     const int b = blockIdx.y;
     const int cells = grid * grid;
-    const int64_t base = (int64_t)b * C * cells;
+    const int64_t plane = (int64_t)rs.H * rs.W;
+    const int64_t base = (int64_t)b * C * plane;
     const int64_t *kn = knn + (int64_t)(b % views) * K * 2;
-    for (int t = threadIdx.x; t < C * kEccvMaxK; t += 256) {
-        const int c = t >> 4, kk = t & 15;
-        float v = 0.f;
-        if (kk < K) v = f2r[base + (int64_t)c * cells + (int)kn[2 * kk + 1] * grid + (int)kn[2 * kk]];
-        sm[t] = v;
+    {
+        // thread t fills tm[c][kk] for kk = t & 15: its keypoint's taps are computed once
+        const int kk = threadIdx.x & 15;
+        const int64_t kx = kk < K ? kn[2 * kk] : -1, ky = kk < K ? kn[2 * kk + 1] : -1;
+        const bool on_grid = kx >= 0 && kx < grid && ky >= 0 && ky < grid;
+        const Taps tk = make_taps(rs, on_grid ? (int)ky : 0, on_grid ? (int)kx : 0);
+        for (int t = threadIdx.x; t < C * kEccvMaxK; t += 256)
+            sm[t] = on_grid ? sample(f2 + base + (int64_t)(t >> 4) * plane, tk) : 0.f;
     }
     __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= cells) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * kEccvCells + lane;
+    const bool live = p < cells;
     float acc[kEccvMaxK];
 #pragma unroll
     for (int kk = 0; kk < kEccvMaxK; ++kk) acc[kk] = 0.f;
-    const float *col = f1r + base + p;
+    const Taps tp = make_taps(rs, (live ? p : 0) / grid, (live ? p : 0) % grid);
+    const float *col = f1 + base;
     const float4 *tm4 = reinterpret_cast<const float4 *>(sm);
     const int groups = (K + 3) >> 2;
     auto channel = [&](int c, float v) {
@@ -122,18 +191,28 @@ __global__ __launch_bounds__(256) void corr_eccv_tile_kernel(const float *__rest
             }
         }
     };
-    int c = 0;
-    for (; c + 8 <= C; c += 8) {
+    const int per = (C + 3) / 4;
+    const int c_end = min(C, (wave + 1) * per);
+    int c = wave * per;
+    for (; c + 8 <= c_end; c += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * cells];
+        for (int u = 0; u < 8; ++u) v[u] = sample(col + (int64_t)(c + u) * plane, tp);
 #pragma unroll
         for (int u = 0; u < 8; ++u) channel(c + u, v[u]);
     }
-    for (; c < C; ++c) channel(c, col[(int64_t)c * cells]);
+    for (; c < c_end; ++c) channel(c, sample(col + (int64_t)c * plane, tp));
+    if (wave > 0)
 #pragma unroll
-    for (int kk = 0; kk < kEccvMaxK; ++kk)
-        if (kk < K) out[((int64_t)b * K + kk) * cells + p] = fmaxf(acc[kk], 0.f);
+        for (int kk = 0; kk < kEccvMaxK; ++kk) red[wave - 1][kk][lane] = acc[kk];
+    __syncthreads();
+    if (wave == 0 && live)
+#pragma unroll
+        for (int kk = 0; kk < kEccvMaxK; ++kk)
+            if (kk < K) {
+                const float v = ((acc[kk] + red[0][kk][lane]) + red[1][kk][lane]) + red[2][kk][lane];
+                out[((int64_t)b * K + kk) * cells + p] = fmaxf(v, 0.f);
+            }
 }
 
 // one block per (b, k): out[b][k][:] (relu'd correlations) / sum exp * 10, as corr_eccv_kernel ends
@@ -146,24 +225,29 @@ __global__ __launch_bounds__(256) void corr_eccv_scale_kernel(float *__restrict_
     for (int p = threadIdx.x; p < cells; p += 256) o[p] = o[p] / denom * 10.f;
 }
 
-// one block per (b, 64 columns of the second map); all rows p of the first map
-__global__ __launch_bounds__(256) void corr_acmm_kernel(const float *__restrict__ f1r, const float *__restrict__ f2r,
-                                                        const float *__restrict__ mask, int C, int grid, int H,
-                                                        int W, float *__restrict__ out) {
+// one block per (b, 64 columns of the second map); all rows p of the first map (grids whose cell count is
+// not a multiple of 4: the MFMA kernel below takes the others); the maps are resampled while they are read
+__global__ __launch_bounds__(256) void corr_acmm_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                        const float *__restrict__ mask, int C, int grid, Resample rs,
+                                                        float *__restrict__ out) {
     __shared__ float part[4][64];
     const int b = blockIdx.y;
     const int cells = grid * grid;
+    const int H = rs.H, W = rs.W;
+    const int64_t plane = (int64_t)H * W;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rg = threadIdx.x >> 6;          // row group: rows p = rg, rg+4, ...
     const bool live = col < cells;
-    const int64_t base = (int64_t)b * C * cells;
+    const int64_t base = (int64_t)b * C * plane;
+    const Taps tc = make_taps(rs, (live ? col : 0) / grid, (live ? col : 0) % grid);
     float *o = out + (int64_t)b * cells * cells;
     float sumsq = 0.f;
     for (int p = rg; p < cells; p += 4) {
         float acc = 0.f;
+        const Taps tp = make_taps(rs, p / grid, p % grid);
         if (live)
             for (int c = 0; c < C; ++c)
-                acc = fmaf(f1r[base + (int64_t)c * cells + p], f2r[base + (int64_t)c * cells + col], acc);
+                acc = fmaf(sample(f1 + base + (int64_t)c * plane, tp), sample(f2 + base + (int64_t)c * plane, tc), acc);
         acc = fmaxf(acc, 0.f);
         sumsq = fmaf(acc, acc, sumsq);
         if (live) o[(int64_t)p * cells + col] = acc;
@@ -200,6 +284,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kCT = 128;   // tile edge
 constexpr int kCK = 16;    // channels per LDS stage
 
+// Operands: maps already at the grid's size (resample2_kernel below brings them there in one launch for
+// both maps).  Resampling inside this loader was measured and dropped: in an all-pairs product every
+// operand element is staged by 7 tiles at the reference's 28 x 28 grid, so the 4-tap gather was done 7
+// times over (83 us against 30 us + one 9 us resampling launch).
 __global__ __launch_bounds__(256) void corr_acmm_gemm_kernel(const float *__restrict__ f1r,
                                                              const float *__restrict__ f2r, int C, int cells,
                                                              float *__restrict__ out,
@@ -334,28 +422,20 @@ extern "C" int ispa_corr_map_eccv_views(const float *f1, const float *f2, const 
     ISPA_REQUIRE(C <= 8192 && (int64_t)B * V <= 65535, "C or B x V too large");
     if (B == 0 || K == 0) return ISPA_OK;
     ISPA_REQUIRE(f1 && f2 && knn && out, "null pointer");
-    ISPA_REQUIRE(workspace || (H == grid && W == grid), "workspace is null but the maps need resizing");
+    (void)workspace;                                  // the maps are resampled while they are read
     hipStream_t s = (hipStream_t)stream;
     const int items = B * V;
-    const float *f1r = f1, *f2r = f2;
-    if (H != grid || W != grid) {
-        // (a map already at the grid's size is its own resize: weights 1 and 0 exactly)
-        float *r1 = workspace, *r2 = workspace + (int64_t)items * C * grid * grid;
-        if (int rc = launch_resize(f1, (int64_t)items * C, H, W, grid, grid, r1, s)) return rc;
-        if (int rc = launch_resize(f2, (int64_t)items * C, H, W, grid, grid, r2, s)) return rc;
-        f1r = r1;
-        f2r = r2;
-    }
+    const Resample rs = make_resample(H, W, grid, grid);
     const int cells = grid * grid;
     const size_t tile_lds = (size_t)C * kEccvMaxK * sizeof(float);
     const ispa::TimingSlot timed = ispa::timing_begin(s);
-    if (cells >= 2048 && K <= kEccvMaxK && tile_lds <= 64 * 1024) {
-        hipLaunchKernelGGL(corr_eccv_tile_kernel, dim3((cells + 255) / 256, items), dim3(256), tile_lds, s, f1r, f2r,
-                           knn, V, C, grid, K, out);
+    if (K <= kEccvMaxK && tile_lds <= 48 * 1024) {
+        hipLaunchKernelGGL(corr_eccv_tile_kernel, dim3((cells + kEccvCells - 1) / kEccvCells, items), dim3(256), tile_lds, s, f1, f2, knn,
+                           V, C, grid, rs, K, out);
         hipLaunchKernelGGL(corr_eccv_scale_kernel, dim3(K, items), dim3(256), 0, s, out, cells, K);
     } else {
-        hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, items), dim3(256), (C + 4) * sizeof(float), s, f1r, f2r, knn, V,
-                           C, grid, K, out);
+        hipLaunchKernelGGL(corr_eccv_kernel, dim3(K, items), dim3(256), (C + 4) * sizeof(float), s, f1, f2, knn, V, C,
+                           grid, rs, K, out);
     }
     ispa::timing_end(timed, s);
     return ispa::check_launch("corr_eccv_kernel");
@@ -376,25 +456,32 @@ extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float 
     ISPA_REQUIRE(f1 && f2 && mask && out && workspace, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int cells = grid * grid;
-    float *f1r = workspace, *f2r = workspace + (int64_t)B * C * cells;
-    if (int rc = launch_resize(f1, (int64_t)B * C, H, W, grid, grid, f1r, s)) return rc;
-    if (int rc = launch_resize(f2, (int64_t)B * C, H, W, grid, grid, f2r, s)) return rc;
+    const Resample rs = make_resample(H, W, grid, grid);
     if (cells % 4 == 0) {
-        // MFMA product + deterministic column normalisation; the column partials live behind the two
-        // resized maps in the workspace
+        // one launch brings both maps to the grid's size (skipped when they are there already), then the
+        // MFMA product and the deterministic column normalisation; workspace = resampled maps + partials
         const int ptiles = (cells + kCT - 1) / kCT;
-        float *colsq = workspace + 2 * (int64_t)B * C * cells;
+        const float *f1r = f1, *f2r = f2;
+        float *colsq = workspace;
+        if (H != grid || W != grid) {
+            float *r1 = workspace, *r2 = workspace + (int64_t)B * C * cells;
+            colsq = workspace + 2 * (int64_t)B * C * cells;
+            hipLaunchKernelGGL(resample2_kernel, dim3(ispa::blocks_for((int64_t)B * C * cells, 256, 1ll << 30), 2),
+                               dim3(256), 0, s, f1, f2, (int64_t)B * C, grid, rs, r1, r2);
+            if (int rc = ispa::check_launch("resample2_kernel")) return rc;
+            f1r = r1;
+            f2r = r2;
+        }
         const ispa::TimingSlot timed = ispa::timing_begin(s);
         hipLaunchKernelGGL(corr_acmm_gemm_kernel, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells, out,
                            colsq);
         ispa::timing_end(timed, s);
         if (int rc = ispa::check_launch("corr_acmm_gemm_kernel")) return rc;
-        hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, 16, B), dim3(256), 0, s, out, colsq,
+        hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, (cells + 7) / 8, B), dim3(256), 0, s, out, colsq,
                            2 * ptiles, mask, grid, H, W);
         return ispa::check_launch("corr_acmm_scale_kernel");
     }
-    hipLaunchKernelGGL(corr_acmm_kernel, dim3((cells + 63) / 64, B), dim3(256), 0, s, f1r, f2r, mask, C, grid, H, W,
-                       out);
+    hipLaunchKernelGGL(corr_acmm_kernel, dim3((cells + 63) / 64, B), dim3(256), 0, s, f1, f2, mask, C, grid, rs, out);
     return ispa::check_launch("corr_acmm_kernel");
 }
 

@@ -119,6 +119,56 @@ __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, 
     }
 }
 
+// ISPA_NN_NORMALIZE: L2NormLayer.forward (ucn_code/lib/layers/l2norm_layer.py:18-29) fused into the norms
+// pass.  y = x / sqrt(sum_c x^2) with the arithmetic of ispa_l2norm (float32 fmaf chain over channels,
+// sqrtf, division), written to a copy that the later passes read, and in the same sweep the float64 norms
+// of y that nn_norms_kernel would compute from that copy: the call returns what ispa_l2norm on both maps
+// followed by ispa_nn_topk returns, bit for bit, with one pass over the inputs less.
+__global__ __launch_bounds__(256) void nn_l2norm_norms_kernel(const float *__restrict__ x, int C, int64_t n,
+                                                              float *__restrict__ y, float *__restrict__ nh,
+                                                              double *__restrict__ sq64, int *__restrict__ maxbits) {
+    const int b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (j < n) {
+        const float *col = x + (int64_t)b * C * n + j;
+        float *dst = y + (int64_t)b * C * n + j;
+        float s32 = 0.f;
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s32 = fmaf(v[u], v[u], s32);
+        }
+        for (; c < C; ++c) s32 = fmaf(col[(int64_t)c * n], col[(int64_t)c * n], s32);
+        const float norm = sqrtf(s32);
+        for (c = 0; c + 8 <= C; c += 8) {          // second sweep: the column is in cache
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(c + u) * n] / norm;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dst[(int64_t)(c + u) * n] = v[u];
+                s = fma((double)v[u], (double)v[u], s);
+            }
+        }
+        for (; c < C; ++c) {
+            const float v = col[(int64_t)c * n] / norm;
+            dst[(int64_t)c * n] = v;
+            s = fma((double)v, (double)v, s);
+        }
+        nh[(int64_t)b * n + j] = (float)(-0.5 * s);
+        sq64[(int64_t)b * n + j] = s;
+    }
+    if (maxbits) {
+        float m = __double2float_ru(s);             // NaN (an all-zero column: 0 / 0) is dropped by fmaxf
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_int(m));
+    }
+}
+
 // Four consecutive cells per thread (16-byte loads for float, 8-byte for bfloat16): same sums in the
 // same channel order, wider memory transactions.  Needs n % 4 == 0 and 16-byte aligned rows.
 template <typename T>
@@ -2307,12 +2357,16 @@ struct Plan {
     int n_qtiles, nsplit, nparts, ktemplate;
     int64_t refs_per_split;
     size_t off_qnh, off_rnh, off_q64, off_r64, off_rmax, off_count, off_pcount, off_list, off_plist, off_llist, off_pval, off_pidx, total;
+    bool normalize;          // ISPA_NN_NORMALIZE: float32 inputs are L2-normalised into copies first
+    size_t off_yq, off_yr;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
+Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
+    const int dtype = dtype_and_flags & ~ISPA_NN_NORMALIZE;
+    p.normalize = (dtype_and_flags & ISPA_NN_NORMALIZE) != 0 && dtype != ISPA_BF16;
     const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0 && nr < (1 << 27);   // 32-bit lane offsets
     p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && C <= 256;
     p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 256 && k == 1;
@@ -2377,6 +2431,11 @@ Plan make_plan(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
         p.off_qlo = take(sizeof(uint16_t) * (size_t)B * C * nq);
         p.off_rhi = take(sizeof(uint16_t) * (size_t)B * C * nr);
         p.off_rlo = take(sizeof(uint16_t) * (size_t)B * C * nr);
+    }
+    p.off_yq = p.off_yr = 0;
+    if (p.normalize) {
+        p.off_yq = take(sizeof(float) * (size_t)B * C * nq);
+        p.off_yr = take(sizeof(float) * (size_t)B * C * nr);
     }
     p.total = off;
     return p;
@@ -2457,7 +2516,20 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
     uint16_t *qhi = (uint16_t *)(ws + p.off_qhi), *qlo = (uint16_t *)(ws + p.off_qlo);
     uint16_t *rhi = (uint16_t *)(ws + p.off_rhi), *rlo = (uint16_t *)(ws + p.off_rlo);
-    if (p.split) {
+    bool norms_done = false;
+    if (p.normalize && sizeof(T) == 4) {
+        // L2-normalised copies of both maps + their norms in one sweep; everything below reads the copies
+        float *yq = (float *)(ws + p.off_yq), *yr = (float *)(ws + p.off_yr);
+        hipLaunchKernelGGL(nn_l2norm_norms_kernel, dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(q), C, nq, yq, qnh, q64, (int *)nullptr);
+        hipLaunchKernelGGL(nn_l2norm_norms_kernel, dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(r), C, nr, yr, rnh, r64, rmax);
+        q = reinterpret_cast<const T *>(yq);
+        r = reinterpret_cast<const T *>(yr);
+        norms_done = !p.split;                       // the split filter still needs its hi / lo images
+    }
+    if (norms_done) {
+    } else if (p.split) {
         const float *qf = reinterpret_cast<const float *>(q), *rf = reinterpret_cast<const float *>(r);
         hipLaunchKernelGGL(nn_split_norms_kernel, dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, qf, C, nq, qhi,
                            qlo, qnh, q64, (int *)nullptr);
@@ -2644,9 +2716,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
 extern "C" size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
-    if (dtype != ISPA_F32 && dtype != ISPA_BF16 && dtype != ISPA_F32_SPLIT) return 0;
+    const int base = dtype & ~ISPA_NN_NORMALIZE, flag = dtype & ISPA_NN_NORMALIZE;
+    if (base != ISPA_F32 && base != ISPA_BF16 && base != ISPA_F32_SPLIT) return 0;
+    if (flag && base == ISPA_BF16) return 0;
     const size_t a = make_plan(dtype, B, C, nq, nr, k).total;
-    const size_t b = make_plan(ISPA_F32, B, C, nq, nr, k).total;     // the plan a call may fall back to
+    const size_t b = make_plan(ISPA_F32 | flag, B, C, nq, nr, k).total;   // the plan a call may fall back to
     return a > b ? a : b;
 }
 
@@ -2723,8 +2797,11 @@ int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64
                  (long long)nr);
     ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31) && B <= 65535, "problem too large");
     ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
+    const int flags = dtype & ISPA_NN_NORMALIZE;
+    dtype &= ~ISPA_NN_NORMALIZE;
     ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16 || dtype == ISPA_F32_SPLIT, "unknown dtype %d", dtype);
-    Plan p = make_plan(dtype, B, C, nq, nr, k);
+    ISPA_REQUIRE(!(flags && dtype == ISPA_BF16), "ISPA_NN_NORMALIZE takes float32 features");
+    Plan p = make_plan(dtype | flags, B, C, nq, nr, k);
     if (p.bf16_mfma && (((uintptr_t)q | (uintptr_t)r) % 16 != 0)) {
         p = make_plan(ISPA_F32, B, C, nq, nr, k);       // unaligned bf16 input: converting tile loader
         p.bf16_mfma = false;

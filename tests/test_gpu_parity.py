@@ -489,6 +489,30 @@ def _unit(rs, shape):
     return x / np.sqrt((x ** 2).sum(1, keepdims=True))
 
 
+def test_nn_fused_l2norm_prologue(pea):
+    """dense_nn(normalize=True) = L2NormLayer (l2norm_layer.py:18-29) + KNN in one call: bit-identical to
+    l2norm() followed by dense_nn(), and equal to the oracle chain (oracle.correlation.l2norm, then
+    cnative.nn_exact on ITS normalised features) wherever the two float32 normalisations agree."""
+    rs = np.random.RandomState(71)
+    for (b, c, nq, nr, k, flt) in ((2, 128, 1024, 2048, 1, "native"), (1, 33, 130, 517, 5, "native"),
+                                   (2, 64, 264, 520, 1, "split")):
+        q = (rs.randn(b, c, nq) * rs.uniform(0.2, 5.0, (b, 1, nq))).astype(np.float32)
+        r = (rs.randn(b, c, nr) * rs.uniform(0.2, 5.0, (b, 1, nr))).astype(np.float32)
+        d0, i0 = pea.correspondence.dense_nn(pea.correspondence.l2norm(q), pea.correspondence.l2norm(r), k, filter=flt)
+        d1, i1 = pea.correspondence.dense_nn(q, r, k, filter=flt, normalize=True)
+        assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32))
+        qn, rn = pea.correspondence.l2norm(q), pea.correspondence.l2norm(r)
+        assert np.allclose(qn, ocorr.l2norm(q), rtol=1e-6, atol=1e-7)
+        for p in range(b):
+            want_i, want_d = cnative.nn_exact(qn[p], rn[p], k, 1)       # exact for the normalised features
+            assert np.array_equal(i1[p], want_i)
+            assert np.all(np.abs(d1[p] - want_d) <= 1e-4 * np.abs(want_d))
+    with pytest.raises(ValueError):
+        import torch
+        pea.correspondence.dense_nn(torch.zeros(1, 32, 8, device="cuda", dtype=torch.bfloat16),
+                                    torch.zeros(1, 32, 8, device="cuda", dtype=torch.bfloat16), normalize=True)
+
+
 @pytest.mark.parametrize("k", [1, 5, 8])
 def test_nn_small_ragged(pea, k):
     rs = np.random.RandomState(k)
@@ -825,6 +849,35 @@ def test_nn_full_size_properties(pea):
     assert bool((d5[:, 1:, :] >= d5[:, :-1, :]).all())       # sorted ascending
 
 
+def test_nn_config3_bf16_one_gpu_share(pea):
+    """BASELINE config 3 at one GPU's share: 512 pairs of 64x64x128 bfloat16 features in one call.
+    Queries are a permutation of the references (every query must find itself at distance exactly 0),
+    except in 4 pairs, which hold independent features and are checked against the oracle on the rounded
+    inputs (indices exact, distances 1e-4 relative)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(33)
+    b, c, n = 512, 128, 4096
+    r = torch.randn(b, c, n, device="cuda", generator=g)
+    r = (r / r.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    perm = torch.stack([torch.randperm(n, device="cuda", generator=g) for _ in range(b)])
+    q = torch.gather(r, 2, perm[:, None, :].expand(-1, c, -1)).contiguous()
+    free = [0, 171, 340, 511]
+    fresh = torch.randn(len(free), c, n, device="cuda", generator=g)
+    q[free] = (fresh / fresh.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+    dist, ind, st = pea.correspondence.dense_nn(q, r, 1, index_base=0, return_stats=True)
+    same = torch.ones(b, dtype=torch.bool, device="cuda")
+    same[free] = False
+    assert torch.equal(ind[same, 0, :].long(), perm[same])
+    assert float(dist[same].abs().max()) == 0.0
+    for i in free:
+        want_i, want_d = cnative.nn_exact(q[i].float().cpu().numpy(), r[i].float().cpu().numpy(), 1, 0)
+        assert np.array_equal(ind[i].cpu().numpy(), want_i)
+        assert np.all(np.abs(dist[i].cpu().numpy() - want_d) <= 1e-4 * np.abs(want_d))
+    # a second run gives the same bits (the partial lists are merged in a fixed order)
+    dist2, ind2 = pea.correspondence.dense_nn(q, r, 1, index_base=0)
+    assert torch.equal(ind, ind2) and torch.equal(dist.view(torch.int32), dist2.view(torch.int32))
+
+
 def test_nn_config5_full_size_properties(pea):
     """3 template views x (128x128 grid, 256-d), top-5: the largest BASELINE configuration."""
     import torch
@@ -994,20 +1047,21 @@ def test_corr_eccv_large_grid(pea):
 
 
 def test_corr_eccv_tiled_and_single_block_paths_agree(pea):
-    """Large grids take the tiled kernel (up to 16 keypoints), anything else one block per keypoint:
-    same fmaf chains and the same summation order, so the maps must agree bit for bit; plus resized
-    inputs, a channel count off the unroll, several views, against the oracle."""
+    """Up to 16 keypoints take the tiled kernel (a cell's correlation = four partial chains over channel
+    quarters), more take one block per keypoint (one chain): the maps agree to float32 rounding; plus
+    resampled inputs, a channel count off the unroll, several views, against the oracle."""
     rs = np.random.RandomState(14)
     f1 = _unit(rs, (2, 37, 96, 96))
     f2 = _unit(rs, (2, 37, 96, 96))
     knn17 = rs.randint(0, 48, (17, 2))
-    layer = pea.correspondence.CorrelationMapLayer(grid=48)              # 2304 cells, resized from 96 x 96
+    layer = pea.correspondence.CorrelationMapLayer(grid=48)              # 2304 cells, resampled from 96 x 96
     single = layer.forward(f1, f2, knn17)                                 # 17 keypoints: one block per keypoint
     tiled = layer.forward(f1, f2, knn17[:16])
-    assert np.array_equal(single[:, :16], tiled)
+    assert np.allclose(single[:, :16], tiled, rtol=1e-5, atol=1e-9)
     assert np.allclose(tiled, ocorr.correlation_map_eccv(f1, f2, knn17[:16], grid=48), rtol=1e-4, atol=1e-9)
+    assert np.allclose(single, ocorr.correlation_map_eccv(f1, f2, knn17, grid=48), rtol=1e-4, atol=1e-9)
     tiled3 = layer.forward(f1, f2, knn17[:3])
-    assert np.array_equal(single[:, :3], tiled3)
+    assert np.array_equal(tiled[:, :3], tiled3)                           # the same kernel, fewer keypoints
     fi, fj = _unit(rs, (2, 3, 64, 64, 64)), _unit(rs, (2, 3, 64, 64, 64))
     knn = rs.randint(0, 64, (3, 10, 2))
     got = pea.correspondence.CorrelationMapLayer(grid=64).forward_views(fi, fj, knn)
