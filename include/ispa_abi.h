@@ -100,7 +100,8 @@ int ispa_project_prune(const double *pts, int64_t n, const double *cams, int n_p
  * uv1, uv2 (n_map,3,n) f64 crop coordinates of pose 1 / pose 2; truth (n_map,n) = truth_1.
  * For every kept point in index order: flow[v-s:v+s, u-s:u+s, :] = (uv2-uv1)[:2] with Python
  * slice semantics, i.e. per pixel the kept point with the HIGHEST index wins.
- * owner_ws (n_map, side*side) int32 scratch; flow (n_map, side, side, 2) f64. */
+ * owner_ws (n_map, side*side) int32 scratch, needed (and touched) only for maps of more than 200704 pixels
+ * (side > 448), may be NULL otherwise; flow (n_map, side, side, 2) f64. */
 int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
                     int n_map, int spread, int side, int32_t *owner_ws, double *flow,
                     void *stream);
@@ -166,9 +167,13 @@ int ispa_zbuffer_tiled(const double *pt_render, int64_t n, int n_pose, int H, in
  * (float) or ISPA_BF16 (bfloat16 bits).  For every query column the k references with the
  * smallest squared L2 distance, ordered by (distance, index); the index order is EXACT with
  * respect to float64 arithmetic on the given inputs (MFMA filter pass + float64 re-scoring of
- * every query whose filter margin is inside the rounding bound).
+ * every query whose filter margin is inside the rounding bound).  Features must be finite: a NaN or
+ * infinity in a column makes the results for that column (and, in a reference column, possibly for
+ * every query of the pair) unspecified; no memory outside the outputs is touched.
  * idx (B,k,nq) int32 = flat reference index + index_base (the reference's layer is 1-based);
- * dist (B,k,nq) f32 squared distances; stats (optional, 4 int32): [0] = queries re-scored
+ * dist (B,k,nq) f32 squared distances, within 1e-4 relative of the float64 value with no absolute floor
+ * (a distance the filter score cannot give to that accuracy is recomputed in float64: an exact match
+ * returns 0.0); stats (optional, 4 int32): [0] = queries re-scored
  * against every reference in float64, [1] = queries settled by float64 re-scoring of the few
  * references that the filter could not separate.
  * ISPA_F32_SPLIT takes the same float32 arrays as ISPA_F32 and returns the same exact index order;

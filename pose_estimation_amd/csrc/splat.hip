@@ -371,11 +371,14 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
     ISPA_REQUIRE(n >= 0 && n_map >= 0 && n < (1ll << 31) - 1, "bad point count");
     ISPA_REQUIRE(side > 0 && side <= 16384 && spread >= 0 && spread <= 64, "bad side/spread");
     if (n_map == 0) return ISPA_OK;
-    ISPA_REQUIRE(flow && (owner_ws || side <= kBandPixels), "null pointer");
+    // up to 8 LDS bands per map (side <= 448): each band block scans all points once, no scratch image;
+    // larger maps take one global atomic per covered pixel on the owner image instead of hundreds of scans
+    const bool banded = (int64_t)side * side <= 8ll * kBandPixels;
+    ISPA_REQUIRE(flow && (owner_ws || banded), "null pointer (maps of more than %d pixels need owner_ws)", 8 * kBandPixels);
     ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)side * side;
-    if (side <= kBandPixels) {
+    if (banded) {
         // banded LDS path (owner_ws is not touched)
         ISPA_REQUIRE(n == 0 || (uv1 && uv2 && truth), "null pointer");
         const int band_rows = kBandPixels / side;

@@ -29,7 +29,8 @@ def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
     if single:
         a, b, t = a[None], b[None], t[None]
     n_map, _, n = a.shape
-    owner = dv.empty((n_map, side * side), torch.int32)
+    # maps of up to 8 x 25088 pixels (side <= 448) run the banded LDS kernel, which needs no owner image
+    owner = None if side * side <= 8 * 25088 else dv.empty((n_map, side * side), torch.int32)
     flow = dv.empty((n_map, side, side, 2), torch.float64)
     _abi.check(_abi.lib.ispa_flow_splat(dv.ptr(a), dv.ptr(b), dv.ptr(t), n, n_map, int(spread), int(side),
                                         dv.ptr(owner), dv.ptr(flow), dv.stream_ptr()))
@@ -73,8 +74,11 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
             h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, SPREAD,
             dv.ptr(flow), dv.stream_ptr()))
         return dv.back(flow, as_tensor)
-    truth1, uv1 = run_proj.project_prune(pts, cams1, depth, crops)
-    _, uv2 = run_proj.project_prune(pts, cams2, depth, crops)
+    if depth.shape[0] not in (1, n_map):
+        raise ValueError("need one depth map per render or a single shared one")
+    shared = depth[0] if depth.shape[0] == 1 else depth       # a 2-D map is shared by all poses
+    truth1, uv1 = run_proj.project_prune(pts, cams1, shared, crops)
+    _, uv2 = run_proj.project_prune(pts, cams2, shared, crops)
     flow = flow_splat(uv1, uv2, truth1)
     return dv.back(flow, as_tensor)
 

@@ -4,30 +4,23 @@ Script entry point of data_creator/make_disparity_syn.py:17-80: for every render
 template model under render_final/, write disparity/<image stem>.npy = (224,224,2) float64 flow.
 The per-image body runs as one fused HIP launch per batch of renders.
 
-Inputs the reference gets from trimesh / OpenEXR are read from caches here: the 100k surface
-samples from sample_points/<synset>_<model>.npy (the file the reference itself falls back to,
-make_disparity_syn.py:32) unless trimesh is installed, and depth images through
-run_proj.get_depthmap_from_exr (an .npy next to the .exr, or OpenEXR if installed)."""
+The 100k surface samples come from run_proj.get_keypoints (an area-weighted sampler over the model's .obj,
+no trimesh needed), or from sample_points/<synset>_<model>.npy when the model file is missing (the reference
+falls back to a fixed file the same way, make_disparity_syn.py:28-32); the depth renders are decoded by
+run_proj.get_depthmap_from_exr (pose_estimation_amd.exr, no OpenEXR needed)."""
 import argparse
 import os
 
 import numpy as np
 
-from . import disparity, global_variables as gv
+from . import disparity, global_variables as gv, run_proj
 
 
 def get_keypoints(model_file, model_synset, template_model, k=100000):
-    """run_proj.get_keypoints (run_proj.py:15-22) when trimesh is importable, else the cached samples."""
-    try:
-        import trimesh
-        mesh = trimesh.load(model_file)
-        if type(mesh) == list:
-            for j in range(1, len(mesh)):
-                mesh[0] = mesh[0].union(mesh[j])
-            mesh = mesh[0]
-        return np.asarray(mesh.sample(int(k), 0))
-    except Exception:
-        return np.load(os.path.join(gv.sample_points_loc, model_synset + "_" + template_model + ".npy"))
+    """run_proj.get_keypoints on the model file, else the cached samples (make_disparity_syn.py:28-32)."""
+    if os.path.exists(model_file):
+        return run_proj.get_keypoints(model_file, k)
+    return np.load(os.path.join(gv.sample_points_loc, model_synset + "_" + template_model + ".npy"))
 
 
 def make_disparity(class_name, batch=64):

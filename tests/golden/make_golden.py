@@ -17,6 +17,7 @@ What is imported from the reference, unmodified:
       return the tensor itself for the duration of the call (line 38 calls it on the mask).
   data_creator/global_variables.py -> skeleton_map, leg_range, syn_template, img_size,
       skeleton_size (the module imports nothing but os); written as tables.json.
+Read as data: data_creator/render_wt_pt_proj/z_map/temp0001.exr (the one depth render the reference ships).
 What cannot be imported here (cv2 / trimesh / OpenEXR / caffe missing) and is therefore
 re-typed below on top of the imported primitives, following the cited lines:
   run_proj.get_3d_to_2d / prune_pts (run_proj.py:24-46), make_disparity's body
@@ -367,8 +368,54 @@ def gen_tables():
     print("tables.json", {k: len(v) for k, v in tables.items()})
 
 
+def gen_exr():
+    """The one depth render the reference ships (data_creator/render_wt_pt_proj/z_map/temp0001.exr, written by
+    Blender: ZIP, FLOAT channels B G R, 540 x 960, depth clamped to 10 as run_render.py:261-300 does).  No other
+    EXR decoder is installed here, so what pins pose_estimation_amd.exr is this real file: its decoded 'R'
+    channel must have Blender's properties (recorded below), and a 48-line crop of the file (the header with a
+    smaller data window + the first three compressed blocks, byte for byte) travels to the GPU box."""
+    import json
+    import struct
+    from pose_estimation_amd import exr
+    src = f"{REF}/data_creator/render_wt_pt_proj/z_map/temp0001.exr"
+    buf = open(src, "rb").read()
+    img = exr.read_exr(buf)
+    r = img["R"]
+    assert r.shape == (540, 960) and np.array_equal(r, img["G"]) and np.array_equal(r, img["B"])
+    assert r.max() == 10.0 and (r == 10.0).mean() > 0.5 and 1.0 < r.min() < 3.0
+    attrs, pos = exr.read_header(buf)
+    nblocks = (540 + 15) // 16
+    offsets = struct.unpack_from(f"<{nblocks}Q", buf, pos)
+    first, keep = 16, 3                                  # 48 scanlines through the object: rows 256 .. 303
+    header = bytearray(buf[:pos])
+    for name in (b"dataWindow\0box2i\0", b"displayWindow\0box2i\0"):
+        at = header.index(name) + len(name) + 4
+        header[at:at + 16] = struct.pack("<4i", 0, 16 * first, 959, 16 * (first + keep) - 1)
+    blocks = [buf[offsets[i]:offsets[i + 1]] for i in range(first, first + keep)]
+    table, at = [], len(header) + 8 * keep
+    for blk in blocks:
+        table.append(at)
+        at += len(blk)
+    crop = bytes(header) + struct.pack(f"<{keep}Q", *table) + b"".join(blocks)
+    with open(os.path.join(HERE, "blender_depth_crop.exr"), "wb") as fh:
+        fh.write(crop)
+    assert np.array_equal(exr.read_exr_channel(crop, "R"), r[256:304]) and (r[256:304] < 10.0).mean() > 0.2
+    probes = [(0, 0), (256, 0), (270, 480), (280, 400), (303, 520), (539, 0)]
+    info = {"shape": [540, 960], "compression": "ZIP", "channels": ["B", "G", "R"],
+            "sha256_R": hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest(),
+            "sha256_R_rows_256_303": hashlib.sha256(np.ascontiguousarray(r[256:304]).tobytes()).hexdigest(),
+            "crop_min": float(r[256:304].min()), "crop_object_pixels": int((r[256:304] < 10.0).sum()),
+            "min": float(r.min()), "max": float(r.max()), "background_fraction": float((r == 10.0).mean()),
+            "probes": [[y, x, float(r[y, x])] for y, x in probes]}
+    with open(os.path.join(HERE, "exr_reference_file.json"), "w") as fh:
+        json.dump(info, fh, indent=1)
+    print("blender_depth_crop.exr", len(crop), "bytes; exr_reference_file.json")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables"]
+    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables", "exr"]
+    if "exr" in which:
+        gen_exr()
     if "acmm" in which:
         gen_acmm()
     if "tables" in which:

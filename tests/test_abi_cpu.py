@@ -92,3 +92,23 @@ def test_spatial_order_host_logic():
     flat = pts.copy()
     flat[:, 2] = 0.5                                          # a degenerate axis must not divide by zero
     assert sorted(run_proj.spatial_order(flat).tolist()) == list(range(5000))
+
+
+def test_surface_sampler_without_trimesh(tmp_path):
+    """run_proj.get_keypoints: area-weighted surface samples of an .obj (a unit cube with one face as a quad and
+    negative indices) lie on the surface and cover the faces in proportion to their area."""
+    import numpy as np
+    from pose_estimation_amd import run_proj
+    obj = tmp_path / "cube.obj"
+    obj.write_text("\n".join(
+        ["v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0 0 2", "v 1 0 2", "v 1 1 2", "v 0 1 2",
+         "f 1 2 3 4", "f 5/1/1 6/2/1 7/3/1 8/4/1", "f 1 2 6 5", "f 2 3 7 6", "f 3 4 8 7", "f -5 -8 -4 -1"]))
+    verts, faces = run_proj.load_obj(str(obj))
+    assert verts.shape == (8, 3) and faces.shape == (12, 3) and faces.min() == 0 and faces.max() == 7
+    pts = run_proj.get_keypoints(str(obj), 40000, seed=1)
+    assert pts.shape == (40000, 3) and np.array_equal(pts, run_proj.get_keypoints(str(obj), 40000, seed=1))
+    on = (np.isclose(pts[:, 0], 0) | np.isclose(pts[:, 0], 1) | np.isclose(pts[:, 1], 0) | np.isclose(pts[:, 1], 1)
+          | np.isclose(pts[:, 2], 0) | np.isclose(pts[:, 2], 2))
+    assert on.all() and pts.min() >= -1e-12 and pts[:, 2].max() <= 2 + 1e-12
+    # areas: bottom / top 1 each, four sides 2 each -> a tenth of the samples on the bottom face
+    assert abs(np.isclose(pts[:, 2], 0).mean() - 0.1) < 0.01

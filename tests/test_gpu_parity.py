@@ -310,6 +310,16 @@ def test_real_image_script_on_a_data_tree(pea, tmp_path):
         gv.processed_image_loc, gv.data_dir = saved
 
 
+def test_make_disparity_unfused_with_one_shared_depth_map(pea, golden_disparity):
+    """fused=False with a single (H,W) depth map for several renders (the fused path always took it)."""
+    z = golden_disparity
+    pts, depth, crop = z["cloud_pts"], z["cloud_depth"], z["cloud_crop"]
+    params = np.stack([z["cloud_params"], z["cloud_params"] + [3.0, 1.0, 0.0, 0.0]])
+    a = pea.disparity.make_disparity_maps(pts, params, depth, [crop, crop], fused=True)
+    b = pea.disparity.make_disparity_maps(pts, params, depth, [crop, crop], fused=False)
+    assert a.shape == (2, 224, 224, 2) and np.array_equal(a, b) and np.array_equal(a[0], z["cloud_flow"])
+
+
 def test_flow_splat_slice_semantics(pea):
     uv = np.array([[0, 1, 2, 223, 230, -5, 100, 50], [50, 50, 50, 223, 10, 60, -3, 50], [1.0] * 8])
     uv2 = uv + np.array([[1.5], [-2.0], [0.0]]) * np.arange(1, 9)
@@ -343,6 +353,21 @@ def test_flow_splat_wild_coordinates(pea, spread, side):
     want = odisp.splat_flow_literal(uv[:, truth], (uv2 - uv)[:, truth], side=side, k=spread)
     assert np.array_equal(got, want)
     assert np.count_nonzero(want) > 0
+
+
+def test_prune_pts_reads_the_exr_depth_render_itself(pea):
+    """run_proj.prune_pts(pt_array, "<render>.png1.exr") as the reference calls it (run_proj.py:33-46,49-57):
+    no .npy cache, no OpenEXR module; the depth image is the crop of the reference's own Blender render."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "blender_depth_crop.exr")
+    depth = pea.run_proj.get_depthmap_from_exr(path)
+    assert depth.shape == (48, 960) and depth.dtype == np.float32
+    ys, xs = np.nonzero(depth < 10.0)
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])                  # a pixel on the object
+    d = float(depth[y, x])
+    pr = np.array([[x, x, x, 5.0], [y, y, y, 5.0], [d, d + 0.1, d + 0.2, 10.0]], dtype=np.float64)
+    truth, same = pea.run_proj.prune_pts(pr, path)
+    assert np.array_equal(truth, og.depth_visibility_array_a(pr, depth)[0].astype(np.float64))
+    assert truth.tolist() == [1.0, 1.0, 0.0, 1.0]                           # |z - depth| <= 0.15; background is 10
 
 
 def test_point_depth_splat(pea, golden_disparity):
@@ -1226,6 +1251,13 @@ def test_timing_hooks(pea):
 def test_errors_are_loud(pea):
     import torch
     from pose_estimation_amd import _abi
+    # a batch of poses against ONE depth / key image would index past the image: refused in Python
+    pr3 = np.zeros((3, 3, 10))
+    with pytest.raises(ValueError):
+        pea.zbuffer.visibility(pr3, np.zeros((540, 960), np.float32))
+    with pytest.raises(ValueError):
+        pea.zbuffer.visibility(pr3, np.zeros((2, 540, 960), np.int64))
+    assert pea.zbuffer.visibility(pr3, np.zeros((3, 54, 96), np.float32)).shape == (3, 10)
     with pytest.raises(_abi.IspaError):
         _abi.check(_abi.lib.ispa_nn_topk(None, None, 0, 1, 8, 16, 16, 1, 1, None, None, None, 0, None, None))
     q = torch.zeros(1, 8, 16, device="cuda")

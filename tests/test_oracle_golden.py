@@ -330,3 +330,49 @@ def test_prune2d_known_answers():
     out = prune2d.make_dense_keypoints_image(sparse, "chair")
     assert out.shape == (2, 130)
     assert prune2d.make_dense_keypoints_image(np.zeros((10, 3)), "chair", dataset="pascal3D") is None
+
+
+def test_exr_reader_on_the_blender_render_and_round_trips(tmp_path):
+    """pose_estimation_amd.exr against (i) a 48-line crop of the one depth render the reference ships (Blender,
+    ZIP, FLOAT B G R; compressed blocks byte for byte, see tests/golden/make_golden.py), whose decoded values
+    were recorded from the whole file, (ii) the whole file when the reference is present, (iii) its own writer
+    for every supported compression, HALF and UINT channels, odd sizes."""
+    import hashlib
+    import json
+    import os
+    from pose_estimation_amd import exr, run_proj
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    info = json.load(open(os.path.join(here, "exr_reference_file.json")))
+    crop = exr.read_exr(os.path.join(here, "blender_depth_crop.exr"))
+    assert sorted(crop) == info["channels"] and crop["R"].shape == (48, 960) and crop["R"].dtype == np.float32
+    assert hashlib.sha256(crop["R"].tobytes()).hexdigest() == info["sha256_R_rows_256_303"]
+    assert np.array_equal(crop["R"], crop["G"]) and float(crop["R"].max()) == info["max"] == 10.0
+    assert float(crop["R"].min()) == info["crop_min"] and int((crop["R"] < 10.0).sum()) == info["crop_object_pixels"]
+    for y, x, v in info["probes"]:
+        if 256 <= y < 304:
+            assert float(crop["R"][y - 256, x]) == v
+    full = "/root/reference/data_creator/render_wt_pt_proj/z_map/temp0001.exr"
+    if os.path.exists(full):
+        r = run_proj.get_depthmap_from_exr(full)                  # the reference's entry point, run_proj.py:49-57
+        assert r.shape == tuple(info["shape"]) and r.dtype == np.float32
+        assert hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest() == info["sha256_R"]
+        assert all(float(r[y, x]) == v for y, x, v in info["probes"])
+    rs = np.random.RandomState(3)
+    for comp in ("NONE", "RLE", "ZIPS", "ZIP"):
+        for shape in ((37, 53), (16, 8), (1, 1)):
+            depth = rs.uniform(0.5, 20.0, shape).astype(np.float32)
+            depth[: shape[0] // 2] = 20.0                          # runs of equal bytes for RLE
+            ids = rs.randint(0, 2 ** 31, shape).astype(np.uint32)
+            path = str(tmp_path / f"t_{comp}_{shape[0]}.exr")
+            exr.write_exr(path, {"R": depth, "Z.id": ids}, compression=comp)
+            back = exr.read_exr(path)
+            assert np.array_equal(back["R"], depth) and np.array_equal(back["Z.id"], ids)
+            assert np.array_equal(run_proj.get_depthmap_from_exr(path), depth)
+            exr.write_exr(path, {"R": depth}, compression=comp, half=True)
+            assert np.array_equal(exr.read_exr_channel(path), depth.astype(np.float16).astype(np.float32))
+    exr.write_exr(str(tmp_path / "layer.exr"), {"Image.R": np.ones((4, 4), np.float32)})
+    assert exr.read_exr_channel(str(tmp_path / "layer.exr"), "R").shape == (4, 4)
+    with pytest.raises(KeyError):
+        exr.read_exr_channel(str(tmp_path / "layer.exr"), "Z")
+    with pytest.raises(ValueError):
+        exr.read_exr(b"not an exr file at all")
