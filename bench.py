@@ -65,13 +65,43 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_rate(fn, units_per_call, budget_s, repeats=5, max_calls=400):
+    """`repeats` timed batches of calls within the budget -> (median units/s, calls per batch, seconds used)."""
+    fn()                                                    # warm
+    t0 = time.perf_counter()
+    fn()
+    one = max(time.perf_counter() - t0, 1e-6)
+    per = int(max(1, min(max_calls // repeats, budget_s / repeats / one)))
+    rates, used = [], 0.0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            fn()
+        el = time.perf_counter() - t0
+        used += el
+        rates.append(units_per_call * per / el)
+    return float(np.median(rates)), per, used
+
+
 def cpu_baseline(grid, channels, k, budget_s):
-    """numpy float32 formulation (sgemm + |a|^2+|b|^2-2ab + argmin) on the host cores."""
+    """numpy float32 formulation (sgemm + |a|^2+|b|^2-2ab + argmin) on the host cores: all BLAS threads
+    (the headline figure) and pinned to one thread; five timed batches each, median."""
     from oracle import nn as onn
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         cores = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
+        threadpool_limits = None
         cores = os.cpu_count() or 1
     rs = np.random.RandomState(2)
     n = grid * grid
@@ -79,38 +109,40 @@ def cpu_baseline(grid, channels, k, budget_s):
     r = rs.randn(channels, n).astype(np.float32)
     q /= np.sqrt((q ** 2).sum(0, keepdims=True))
     r /= np.sqrt((r ** 2).sum(0, keepdims=True))
-    onn.nn_sgemm(q, r, k)                                   # warm
-    done, t0 = 0, time.perf_counter()
-    while True:
-        onn.nn_sgemm(q, r, k)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 400:
-            break
-    return {"value": round(done / el, 3), "unit": "pairs/s", "cores": int(cores), "kind": "port",
-            "sample": f"{done} pairs of {grid}x{grid}x{channels} float32 in {el:.1f} s, numpy sgemm + argmin "
-                      f"(oracle.nn.nn_sgemm), BLAS threads = {cores}"}
+    rate, per, used = _median_rate(lambda: onn.nn_sgemm(q, r, k), 1, 0.7 * budget_s)
+    out = {"value": round(rate, 3), "unit": "pairs/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model(),
+           "repeats": 5, "statistic": "median",
+           "sample": f"5 batches of {per} pairs of {grid}x{grid}x{channels} float32 in {used:.1f} s, numpy sgemm + "
+                     f"argmin (oracle.nn.nn_sgemm), BLAS threads = {cores}"}
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1, user_api="blas"):
+            rate1, per1, used1 = _median_rate(lambda: onn.nn_sgemm(q, r, k), 1, 0.3 * budget_s)
+        out["one_core"] = {"value": round(rate1, 3), "unit": "pairs/s", "cores": 1,
+                           "sample": f"5 batches of {per1} pairs in {used1:.1f} s, BLAS pinned to 1 thread"}
+    return out
 
 
 HBM_PEAK_GBS = 8000.0                                     # MI355X_MICROARCH.md
 
 
 def measured_traffic(workload_key, kernel, is_default_shape):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs of this same bench command, gfx950 correction applied by
-    tools/pmc_summary.py); null when this run's shape is not the profiled one."""
+    """HBM bytes per launch of `kernel` and the file they come from: the newest committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs of this same bench command, gfx950 correction applied by
+    tools/pmc_summary.py).  A constant from that profile, NOT a measurement of this run; (None, None) when this
+    run's shape is not the profiled one."""
     if not is_default_shape:
-        return None
+        return None, None
     try:
         import glob
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
         table = json.load(open(newest))[workload_key]
+        src = os.path.relpath(newest, ROOT)
         if kernel in table:
-            return table[kernel]["traffic_bytes"]
+            return table[kernel]["traffic_bytes"], src
         hits = [v["traffic_bytes"] for k, v in table.items() if k.startswith(kernel.replace("_kernel", ""))]
-        return hits[0] if len(hits) == 1 else None
+        return (hits[0], src) if len(hits) == 1 else (None, None)
     except (OSError, KeyError, ValueError, IndexError):
-        return None
+        return None, None
 
 
 def run_geometry(args, torch, dist, world, rank, dev):
@@ -264,20 +296,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
     for _ in range(args.warmup):
         step()
     _abi.check(_abi.lib.ispa_timing_enable(args.steps * recs))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.timed_steps(step, lambda: None, args.steps, 0, torch.cuda.synchronize)
     ms = (ctypes.c_float * (args.steps * recs))()
     cnt = ctypes.c_int(0)
     _abi.check(_abi.lib.ispa_timing_collect(ms, args.steps * recs, ctypes.byref(cnt)))
@@ -293,6 +312,13 @@ def run_geometry(args, torch, dist, world, rank, dev):
         tf = alg_bytes[dom] / (per[dom] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_PEAK_TFLOPS["f32"], 4)}
+    traffic, traffic_src = measured_traffic(
+        args.workload + ("_unfused" if args.unfused else ""),
+        {"project_prune": "project_prune2_kernel", "flow_band": "flow_band_kernel", "project": "project2_kernel",
+         "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_tile_kernel",
+         "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel"}[names[dom]],
+        args.workload == "corr" or (n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
+                                                      else args.maps == 256)))
     out_json = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
         "value": round(units * world * args.steps / elapsed, 2), "unit": unit_name, "n_gpus": world,
@@ -300,18 +326,9 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.workload == "corr" else "f64", "data": "synthetic",
         "config": {"workload": workload, "points": n, "point_order": "hilbert curve (run_proj.spatial_order)" if args.morton else "as generated"},
-        "roofline": dict(roof,
-                     traffic=measured_traffic(args.workload + ("_unfused" if args.unfused else ""),
-                                                 {"project_prune": "project_prune2_kernel",
-                                                  "flow_band": "flow_band_kernel", "project": "project2_kernel",
-                                                  "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_kernel",
-                                                  "corr_acmm_gemm": "corr_acmm_gemm_kernel",
-                                                  "make_disparity": "make_disparity_kernel"}[names[dom]],
-                                                 args.workload == "corr" or (n == 100000 and (
-                                                     args.poses == 3600 if args.workload in ("project", "zbuffer")
-                                                     else args.maps == 256))),
-                     kernel=names[dom], kernel_ms=round(per[dom], 4), work_per_launch=alg_bytes[dom],
-                     all_kernels_ms={f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}),
+        "roofline": dict(roof, traffic=traffic, traffic_source=traffic_src, kernel=names[dom],
+                         kernel_ms=round(per[dom], 4), work_per_launch=alg_bytes[dom],
+                         all_kernels_ms={f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}),
     }
     if not args.no_cpu_baseline and world == 1:
         out_json["cpu_baseline"] = cpu_baseline_geometry(args)
@@ -339,6 +356,7 @@ def cpu_baseline_geometry(args):
             if el >= args.cpu_seconds or done >= 50:
                 break
         return {"value": round(8 * done / el, 3), "unit": "pairs/s", "cores": os.cpu_count() or 1, "kind": "port",
+                "cpu_model": cpu_model(),
                 "sample": f"{done} steps (3 x eccv K=10 + 1 x acmm, B=8) in {el:.1f} s; numpy einsum restatement "
                           f"(oracle.correlation), which contracts only the K needed rows unlike the reference's "
                           f"5-D broadcast"}
@@ -372,12 +390,12 @@ def cpu_baseline_geometry(args):
         if el >= args.cpu_seconds or done >= 50:
             break
     if args.workload == "zbuffer":
-        return {"value": round(done / el, 3), "unit": "pose-maps/s", "cores": 1, "kind": "port",
+        return {"value": round(done / el, 3), "unit": "pose-maps/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                 "sample": f"{done} poses of {n} points in {el:.1f} s; numpy projection + np.minimum.at z-buffer "
                           f"(oracle.zbuffer; this mode has no counterpart in the reference)"}
     what = "make_disparity images" if args.workload == "disparity" else "project+prune poses"
     return {"value": round(done / el, 3), "unit": "maps/s" if args.workload == "disparity" else "pose-maps/s",
-            "cores": 1, "kind": "port",
+            "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{done} {what} of {n} points in {el:.1f} s; numpy projection + per-point Python loops as in "
                       f"the reference (oracle.geometry.depth_visibility_literal, oracle.disparity.splat_flow_literal)"}
 
@@ -453,21 +471,7 @@ def main():
         step()
     drain()
     _abi.check(_abi.lib.ispa_timing_enable(args.steps))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.timed_steps(step, drain, args.steps, 0, torch.cuda.synchronize)
 
     # per-launch duration of the filter kernel, HIP events on the launch stream inside the timed region
     ms = (ctypes.c_float * args.steps)()
@@ -479,31 +483,23 @@ def main():
     # Not part of `value`: the same batch through the bfloat16 path (inputs rounded to bfloat16, results
     # exact for those inputs), reported beside the float32 headline.
     extra = {}
-    if args.dtype == "f32" and not args.no_extra:
-        q16, r16 = q.to(torch.bfloat16), r.to(torch.bfloat16)
+
+    def side_run(fn, n_steps=10):
+        """(elapsed seconds over ranks, mean filter-kernel ms) of n_steps calls of fn, after two warm-up calls."""
         for _ in range(2):
-            pea.correspondence.dense_nn(q16, r16, args.k)
-        n16 = 10
-        _abi.check(_abi.lib.ispa_timing_enable(n16))
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n16):
-            pea.correspondence.dense_nn(q16, r16, args.k)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el16 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([el16], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el16 = float(t.item())
-        ms16 = (ctypes.c_float * n16)()
-        cnt16 = ctypes.c_int(0)
-        _abi.check(_abi.lib.ispa_timing_collect(ms16, n16, ctypes.byref(cnt16)))
+            fn()
+        _abi.check(_abi.lib.ispa_timing_enable(n_steps))
+        el = sharding.timed_steps(fn, lambda: None, n_steps, 0, torch.cuda.synchronize)
+        buf = (ctypes.c_float * n_steps)()
+        got = ctypes.c_int(0)
+        _abi.check(_abi.lib.ispa_timing_collect(buf, n_steps, ctypes.byref(got)))
         _abi.check(_abi.lib.ispa_timing_enable(0))
-        k16 = float(np.mean(ms16[:cnt16.value])) if cnt16.value else float("nan")
+        return el, (float(np.mean(buf[:got.value])) if got.value else float("nan"))
+
+    if args.dtype == "f32" and not args.no_extra:
+        n16 = 10
+        q16, r16 = q.to(torch.bfloat16), r.to(torch.bfloat16)
+        el16, k16 = side_run(lambda: pea.correspondence.dense_nn(q16, r16, args.k), n16)
         tf16 = 2.0 * n * n * c * b / (k16 * 1e-3) / 1e12
         extra["bf16"] = {"value": round(b * world * n16 / el16, 2), "unit": "maps/s", "steps": n16,
                          "ms_per_step": round(el16 / n16 * 1e3, 4), "result_allgather": False,
@@ -512,38 +508,37 @@ def main():
                                       "kernel": "nn_filter", "kernel_ms": round(k16, 4)}}
         del q16, r16
         if args.filter == "native" and args.k == 1:
-            for _ in range(2):
-                pea.correspondence.dense_nn(q, r, 1, filter="split")
-            _abi.check(_abi.lib.ispa_timing_enable(n16))
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n16):
-                pea.correspondence.dense_nn(q, r, 1, filter="split")
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            els = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([els], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                els = float(t.item())
-            _abi.check(_abi.lib.ispa_timing_collect(ms16, n16, ctypes.byref(cnt16)))
-            _abi.check(_abi.lib.ispa_timing_enable(0))
-            ks = float(np.mean(ms16[:cnt16.value])) if cnt16.value else float("nan")
+            els, ks = side_run(lambda: pea.correspondence.dense_nn(q, r, 1, filter="split"), n16)
             extra["f32_inputs_split_bf16_filter"] = {
                 "value": round(b * world * n16 / els, 2), "unit": "maps/s", "steps": n16,
                 "ms_per_step": round(els / n16 * 1e3, 4), "result_allgather": False,
                 "note": "same float32 inputs and the same exact results as the headline; the filter pass contracts "
                         "a bfloat16 hi/lo split on bfloat16 MFMAs (3 MFMAs per tile and k-step)",
                 "kernel": "nn_filter", "kernel_ms": round(ks, 4)}
+        if not args.matches:
+            # the same batch with queries that have close matches (noisy copies of template cells): every returned
+            # distance then takes the float64 refinement, which random features never exercise
+            perm = torch.stack([torch.randperm(n, device=dev, generator=gen) for _ in range(b)])
+            qm = torch.gather(r.view(b, c, n), 2, perm[:, None, :].expand(-1, c, -1)).view(b, c, g, g)
+            qm = qm + 0.02 * torch.randn(b, c, g, g, device=dev, generator=gen)
+            qm = (qm / qm.norm(dim=1, keepdim=True)).contiguous()
+            elm, km = side_run(lambda: pea.correspondence.dense_nn(qm, r, args.k, filter=filt), n16)
+            extra["f32_close_matches"] = {
+                "value": round(b * world * n16 / elm, 2), "unit": "maps/s", "steps": n16,
+                "ms_per_step": round(elm / n16 * 1e3, 4), "result_allgather": False,
+                "note": "queries = noisy copies of template cells: all distances re-scored in float64 (nn_refine_kernel)",
+                "kernel": "nn_filter", "kernel_ms": round(km, 4)}
+            del qm, perm
 
     if rank == 0:
         pairs_total = b * world * args.steps
         flop_per_pair = 2.0 * n * n * c                          # GEMM term of the distance stage
         achieved = flop_per_pair * b / (filt_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS["bf16" if filt == "split" else args.dtype]
+        traffic, traffic_src = measured_traffic(
+            "nn___dtype_" + args.dtype + ("___filter_split" if filt == "split" else ""),
+            "nn_filter_split_kernel" if filt == "split" else "nn_filter_%s_kernel" % args.dtype,
+            (b, g, c, args.k) == (512, 64, 128, 1) and not args.matches)
         out = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
             "value": round(pairs_total / elapsed, 2),
@@ -565,11 +560,7 @@ def main():
                        "features": "queries = noisy copies of template cells" if args.matches else "independent random unit vectors",
                        "result_allgather": bool(gather)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         "traffic": measured_traffic("nn___dtype_" + args.dtype + ("___filter_split" if filt == "split" else ""),
-                                                     "nn_filter_split_kernel" if filt == "split"
-                                                     else "nn_filter_%s_kernel" % args.dtype,
-                                                     (b, g, c, args.k) == (512, 64, 128, 1)),
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "nn_filter", "kernel_ms": round(filt_ms, 4),
                          "flop_per_launch": flop_per_pair * b},
         }

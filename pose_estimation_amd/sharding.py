@@ -22,61 +22,93 @@ def shard_sizes(total, world_size):
             for r in range(world_size)]
 
 
+def _padded_block(local, biggest):
+    if local.shape[0] == biggest:
+        return local.contiguous()
+    padded = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    return padded
+
+
+def _unpad(out, sizes, biggest):
+    """(world * biggest, ...) gathered blocks -> (total, ...) in unit order."""
+    if all(s == biggest for s in sizes):
+        return out
+    return torch.cat([out[r * biggest:r * biggest + s] for r, s in enumerate(sizes)], dim=0)
+
+
 def allgather_results(local, total, group=None):
     """Gather per-rank result blocks (first axis = units of this rank) into the full batch.
 
     `local` is this rank's (n_local, ...) tensor; every rank returns the (total, ...) tensor in
-    unit order.  Uneven shards are padded to the largest block for the collective."""
-    if not (dist.is_available() and dist.is_initialized()):
-        if local.shape[0] != total:
-            raise ValueError("no process group: the local block must be the whole batch")
-        return local
-    world = dist.get_world_size(group)
-    sizes = shard_sizes(total, world)
-    if local.shape[0] != sizes[dist.get_rank(group)]:
-        raise ValueError("local block does not match this rank's shard")
-    biggest = max(sizes)
-    if all(s == biggest for s in sizes):
-        out = torch.empty((world * biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
-    padded = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+    unit order.  One all_gather_into_tensor either way: uneven shards (they differ by at most one
+    unit) are padded to the largest block and the padding is cut out afterwards."""
+    return allgather_results_async(local, total, group).wait()
 
 
 class PendingGather:
-    """Result all-gather in flight (even shards): `wait()` returns the (total, ...) tensor.
+    """Result all-gather in flight: `wait()` returns the (total, ...) tensor.
 
     The collective runs on the communicator's own stream, so kernels of the next batch launched
     meanwhile overlap with it; the object keeps the input block alive until then."""
 
-    def __init__(self, work, out, local):
-        self._work, self._out, self._local = work, out, local
+    def __init__(self, work, out, local, sizes=None, biggest=0):
+        self._work, self._out, self._local, self._sizes, self._biggest = work, out, local, sizes, biggest
 
     def wait(self):
         if self._work is not None:
             self._work.wait()
             self._work = self._local = None
+            if self._sizes is not None:
+                self._out = _unpad(self._out, self._sizes, self._biggest)
+                self._sizes = None
         return self._out
 
 
 def allgather_results_async(local, total, group=None):
     """Start the all-gather of this rank's result block and return a PendingGather.
 
-    Without a process group, or with uneven shards, the gather is done at once (the object is
-    already complete)."""
+    Without a process group the object is already complete (the local block must be the whole batch)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return PendingGather(None, allgather_results(local, total, group), None)
+        if local.shape[0] != total:
+            raise ValueError("no process group: the local block must be the whole batch")
+        return PendingGather(None, local, None)
     world = dist.get_world_size(group)
     sizes = shard_sizes(total, world)
     if local.shape[0] != sizes[dist.get_rank(group)]:
         raise ValueError("local block does not match this rank's shard")
-    if any(s != sizes[0] for s in sizes):
-        return PendingGather(None, allgather_results(local, total, group), None)
-    local = local.contiguous()
-    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)
-    return PendingGather(work, out, local)
+    biggest = max(sizes)
+    block = _padded_block(local, biggest)
+    out = torch.empty((world * biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, block, group=group, async_op=True)
+    return PendingGather(work, out, block, sizes, biggest)
+
+
+def timed_steps(step, drain, steps, warmup, sync, group=None):
+    """The measurement loop of bench.py, shared by every workload and rank: `warmup` untimed steps, then
+    EXACTLY `steps` timed ones between two (barrier + sync()) pairs; `drain()` completes whatever a step left
+    in flight (result gathers) and runs inside the timed region, before the closing barrier.  Returns the
+    elapsed seconds of the slowest rank (MAX over ranks), the same value on every rank.  `sync` waits for
+    the device (torch.cuda.synchronize; a no-op for host-only steps)."""
+    import time
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    for _ in range(warmup):
+        step()
+    drain()
+    if multi:
+        dist.barrier(group=group)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    if multi:
+        dist.barrier(group=group)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        backend = dist.get_backend(group)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    return elapsed

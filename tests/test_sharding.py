@@ -48,6 +48,57 @@ def _worker(rank, world, port, total, q):
     q.put((rank, ok))
 
 
+def _bench_loop_worker(rank, world, port, total, q):
+    """bench.py's own control flow (sharding.timed_steps) with a fake step: the rank's share of `total`
+    units per step, an overlapped result gather per step, rank 1 slower than rank 0."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = _load_sharding()
+    lo, hi = sh.shard_range(total, rank, world)
+    log = {"steps": 0, "gathered": [], "pending": []}
+
+    def step():
+        time.sleep(0.01 * (1 + 2 * rank))                          # rank 1 takes three times as long
+        block = torch.full((hi - lo, 2), float(log["steps"]), dtype=torch.float32)
+        block[:, 1] = torch.arange(lo, hi, dtype=torch.float32)
+        for p in log["pending"]:
+            log["gathered"].append(p.wait())
+        log["pending"] = [sh.allgather_results_async(block, total)]
+        log["steps"] += 1
+
+    def drain():
+        for p in log["pending"]:
+            log["gathered"].append(p.wait())
+        log["pending"] = []
+    elapsed = sh.timed_steps(step, drain, steps=5, warmup=2, sync=lambda: None)
+    ok = log["steps"] == 7 and len(log["gathered"]) == 7 and not log["pending"]
+    for i, g in enumerate(log["gathered"]):                        # every gather complete, in unit order
+        ok = ok and g.shape == (total, 2) and bool((g[:, 0] == i).all()) and torch.equal(g[:, 1], torch.arange(total, dtype=torch.float32))
+    ok = ok and elapsed >= 5 * 0.03 * 0.9                          # the slowest rank sets the time on both
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, round(elapsed, 6)))
+
+
+@pytest.mark.parametrize("total", [8, 7, 3600])
+def test_bench_control_flow_two_ranks_gloo(total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_loop_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[:2] for r in results] == [(0, True), (1, True)]
+    assert results[0][2] == results[1][2]                          # MAX over ranks: the same number everywhere
+
+
 @pytest.mark.parametrize("total", [8, 7])
 def test_allgather_two_ranks_gloo(total):
     with socket.socket() as s:
