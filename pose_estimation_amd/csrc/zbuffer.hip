@@ -39,6 +39,9 @@ constexpr int kRounds = 4;                  // rounds of kZThreads boxes a list 
 constexpr int kCacheVisits = ZB_CACHE;            // chunk visits whose tile offsets pass 1 leaves in LDS for pass 2 (12 KiB)
 constexpr int kGroup = 4;                   // consecutive items taken off the counter at a time
 constexpr unsigned long long kEmptyKey = ~0ull;
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kBoxWhole = 32000;            // |bound| of a box that covers every image (H, W <= 16384)
 constexpr unsigned kNoPixel = 0xffffu;
 
@@ -435,14 +438,21 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
                 const unsigned long long k0 = any ? tile[ly * kTileW + lx] : kEmptyKey;
                 const unsigned long long k1 = any ? tile[ly * kTileW + lx + 1] : kEmptyKey;
                 const int64_t o = img + (int64_t)(ty0 + ly) * W + tx0 + lx;
-                if (packed) *reinterpret_cast<ulonglong2 *>(packed + o) = make_ulonglong2(k0, k1);
-                if (winner)
-                    *reinterpret_cast<int2 *>(winner + o) =
-                        make_int2(k0 == kEmptyKey ? -1 : (int)(uint32_t)k0, k1 == kEmptyKey ? -1 : (int)(uint32_t)k1);
-                if (depth)
-                    *reinterpret_cast<float2 *>(depth + o) =
-                        make_float2(k0 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k0 >> 32)),
-                                    k1 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k1 >> 32)));
+                // streaming stores: the images are written once and not read here, and must not push the
+                // model's points and the box tables out of L2
+                if (packed) {
+                    const u64x2 kk = {k0, k1};
+                    __builtin_nontemporal_store(kk, reinterpret_cast<u64x2 *>(packed + o));
+                }
+                if (winner) {
+                    const i32x2 ww = {k0 == kEmptyKey ? -1 : (int)(uint32_t)k0, k1 == kEmptyKey ? -1 : (int)(uint32_t)k1};
+                    __builtin_nontemporal_store(ww, reinterpret_cast<i32x2 *>(winner + o));
+                }
+                if (depth) {
+                    const f32x2 dd = {k0 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k0 >> 32)),
+                                      k1 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k1 >> 32))};
+                    __builtin_nontemporal_store(dd, reinterpret_cast<f32x2 *>(depth + o));
+                }
             }
         } else {
             for (int e = threadIdx.x; e < th * tw; e += kZThreads) {

@@ -1,14 +1,16 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under gpurun_out/ on the GPU box (run from the repo root):
-#   bash tools/profile_all.sh
-# then, back in the build container:  python tools/profile_collect.py gpurun_out profiles r01
+#   bash tools/profile_all.sh            (ONLY="zbuffer corr" bash tools/profile_all.sh  re-runs just those tags)
+# then, back in the build container:  python tools/profile_collect.py gpurun_out profiles r02
 # One pass per counter set; the PMC passes never combine with API tracing.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+skip() { [ -n "$ONLY" ] && ! [[ " $ONLY " == *" $1 "* ]]; }
 run() {   # tag, bench args...
     local tag=$1; shift
+    skip $tag && return 0
     echo "== $tag: $*"
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$tag -- \
         python3 $R/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_$tag.json 2> $OUT/stats_$tag.err || return 1
@@ -19,6 +21,7 @@ run() {   # tag, bench args...
 }
 sq() {    # tag, bench args...
     local tag=$1; shift
+    skip $tag && return 0
     timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
         SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_${tag}_SQ -- \
         python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> $OUT/pmc_${tag}_SQ.err || return 1
@@ -29,10 +32,13 @@ run nn___dtype_f32___filter_split --workload nn --dtype f32 --filter split --no-
 run project --workload project &&
 run disparity --workload disparity &&
 run zbuffer --workload zbuffer &&
+run zbuffer_unfused --workload zbuffer --unfused --poses 720 &&
 run corr --workload corr &&
+run nn___dtype_f32___matches --workload nn --dtype f32 --matches --no-extra &&
 run nn___config5_bf16_k5 --workload nn --dtype bf16 --grid 128 --channels 256 --k 5 --pairs 24 --no-extra &&
 sq nn___dtype_f32 --workload nn --dtype f32 &&
 sq nn___dtype_bf16 --workload nn --dtype bf16 &&
 sq nn___dtype_f32___filter_split --workload nn --dtype f32 --filter split &&
-cd $R && timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err &&
+sq zbuffer --workload zbuffer &&
+cd $R && { [ -n "$ONLY" ] || timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; } &&
 echo "profile_all: done"
