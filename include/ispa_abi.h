@@ -14,6 +14,10 @@
  *     and is asynchronous with respect to the host;
  *   - return value 0 = ok, negative = ispa_status; ispa_last_error() returns a thread-local
  *     message for the last failing call on the calling thread;
+ *   - one GPU per process: the library holds no communicator and exports no collective.  Shards of
+ *     pairs, maps or poses are independent; the exchange of result records between ranks is the
+ *     caller's (the Python layer uses torch.distributed all_gather_into_tensor over RCCL), because the
+ *     process that owns the ranks also owns their bootstrap and stream ordering;
  *   - arrays are C-ordered; "pt_render" always means the reference's (3, N) float64 layout with
  *     rows [u, v, z] (pt2render.py:6-13), batched as (n_pose, 3, N).
  */
