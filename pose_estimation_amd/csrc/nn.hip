@@ -119,6 +119,42 @@ __global__ __launch_bounds__(256) void nn_norms_kernel(const T *__restrict__ x, 
     }
 }
 
+// Small problems (a single image pair per call): one cell per thread in 64-thread workgroups, so that a
+// few thousand cells still spread over a hundred CUs, and 32 channels of loads in flight per thread (the
+// four-cells-per-thread kernels above would run as 8 workgroups waiting for 4 loads at a time).  Query and
+// reference map in one launch; workgroup (0, 0) also clears the queue counters of the later passes, which
+// saves the separate memset launch.  Same sums in the same channel order as nn_norms_kernel.
+template <typename T>
+__global__ __launch_bounds__(64) void nn_norms_small_kernel(const T *__restrict__ q, const T *__restrict__ r, int C,
+                                                            int64_t nq, int64_t nr, int nbq,
+                                                            float *__restrict__ qnh, double *__restrict__ q64,
+                                                            float *__restrict__ rnh, double *__restrict__ r64,
+                                                            int *__restrict__ zero, int nzero) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int t = threadIdx.x; t < nzero; t += 64) zero[t] = 0;
+    const int b = blockIdx.y;
+    const bool is_q = (int)blockIdx.x < nbq;
+    const int64_t n = is_q ? nq : nr;
+    const int64_t j = (int64_t)(is_q ? blockIdx.x : blockIdx.x - nbq) * 64 + threadIdx.x;
+    if (j >= n) return;
+    const T *col = (is_q ? q : r) + (int64_t)b * C * n + j;
+    double s = 0.0;
+    int c = 0;
+    for (; c + 32 <= C; c += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = load_as_float(col + (int64_t)(c + u) * n);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s = fma((double)v[u], (double)v[u], s);
+    }
+    for (; c < C; ++c) {
+        const double v = (double)load_as_float(col + (int64_t)c * n);
+        s = fma(v, v, s);
+    }
+    (is_q ? qnh : rnh)[(int64_t)b * n + j] = (float)(-0.5 * s);
+    (is_q ? q64 : r64)[(int64_t)b * n + j] = s;
+}
+
 // ISPA_NN_NORMALIZE: L2NormLayer.forward (ucn_code/lib/layers/l2norm_layer.py:18-29) fused into the norms
 // pass.  y = x / sqrt(sum_c x^2) with the arithmetic of ispa_l2norm (float32 fmaf chain over channels,
 // sqrtf, division), written to a copy that the later passes read, and in the same sweep the float64 norms
@@ -2079,6 +2115,199 @@ __global__ __launch_bounds__(kRefineThreads) void nn_refine_kernel(const T *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3e. small problems, top-1: finalize, re-scoring of known contenders and distance refinement in one
+// launch.  nn_finalize_kernel gives a query to one thread, which walks all partial streams (two passes of
+// dependent loads when a margin is small); with a single image pair that is 4096 threads on the whole chip
+// and the kernel lasts as long as the filter pass.  Here a 1024-thread workgroup owns 64 queries: wave w
+// holds the lists of streams w, w + 16, ... in registers (at most kFsParts each), the 16 waves merge through
+// LDS, wave 0 decides like nn_finalize_kernel (same comparisons, same margins), and queries inside the margin
+// get their contenders from the registers the waves still hold; known contenders are re-scored by 16
+// threads per query (exact_d2, as nn_rescore_top1_kernel does), hidden ones go to the float64 pass's queue.
+// Marked distances (close matches) are recomputed on the spot (as nn_refine_kernel does).  The largest
+// reference norm of the pair is reduced here from the float64 norms, so nothing needs a zeroed cell
+// before the norms pass.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFsWaves = 16, kFsParts = 8, kFsCand = 8;
+constexpr int64_t kSmallQueries = 16384, kSmallRefs = 16384;
+
+__device__ __forceinline__ void top2_insert(float x, int code, float &v0, int &c0, float &v1, int &c1) {
+    if (!(x > kAbsent) && x == x) return;                      // absent (NaN falls through)
+    if (x > v1 || (x == v1 && (unsigned)code < (unsigned)c1) || x != x) {
+        v1 = x;
+        c1 = code;
+        if (v1 > v0 || (v1 == v0 && (unsigned)c1 < (unsigned)c0) || v1 != v1) {
+            const float tv = v1;
+            v1 = v0;
+            v0 = tv;
+            const int tc = c1;
+            c1 = c0;
+            c0 = tc;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
+    const float *__restrict__ part_val, const int *__restrict__ part_idx, int nparts, const float *__restrict__ qnh,
+    int C, int64_t nq, int64_t nr, int index_base, float err_rel, const T *__restrict__ q, const T *__restrict__ r,
+    const double *__restrict__ qq64, const double *__restrict__ rr64, float *__restrict__ dist,
+    int *__restrict__ idx, int *__restrict__ amb_count, int *__restrict__ amb_list, int *__restrict__ pair_count,
+    int *__restrict__ pair_list, int *__restrict__ light_count) {
+    __shared__ float s_v[2][kFsWaves][64];
+    __shared__ int s_c[2][kFsWaves][64];
+    __shared__ float s_rmax[kFsWaves];
+    __shared__ float s_lim[64];
+    __shared__ int s_state[64];                  // 0 settled, 1 inside the margin, 2 contenders known, 3 queued
+    __shared__ int s_ncand[64], s_hidden[64];
+    __shared__ int s_cand[64][kFsCand];
+    __shared__ double s_cd[64][kFsCand];
+    __shared__ int s_any;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < nq;
+    const int64_t ii = live ? i : nq - 1;
+    if (tid < 64) {
+        s_state[tid] = 0;
+        s_ncand[tid] = 0;
+        s_hidden[tid] = 0;
+    }
+    if (tid == 0) s_any = 0;
+    // this wave's streams, all loads in flight together
+    float xs[kFsParts][2];
+    int cs[kFsParts][2];
+#pragma unroll
+    for (int e = 0; e < kFsParts; ++e) {
+        const int p = wave + kFsWaves * e;
+        const int pp = p < nparts ? p : nparts - 1;
+        const int64_t o = (((int64_t)b * nparts + pp) * 2) * nq + ii;
+        xs[e][0] = part_val[o];
+        xs[e][1] = part_val[o + nq];
+        cs[e][0] = part_idx[o];
+        cs[e][1] = part_idx[o + nq];
+    }
+    // largest squared reference norm of the pair, rounded up (what the norms pass gives the large-batch path)
+    double m = 0.0;
+    for (int64_t j = tid; j < nr; j += 64 * kFsWaves) m = fmax(m, rr64[(int64_t)b * nr + j]);
+    float mf = __double2float_ru(m);
+    for (int off = 32; off > 0; off >>= 1) mf = fmaxf(mf, __shfl_xor(mf, off));
+    if (lane == 0) s_rmax[wave] = mf;
+    float v0 = kNegInf, v1 = kNegInf;
+    int c0 = -1, c1 = -1;
+#pragma unroll
+    for (int e = 0; e < kFsParts; ++e) {
+        if (wave + kFsWaves * e >= nparts) break;
+        top2_insert(xs[e][0], cs[e][0], v0, c0, v1, c1);
+        top2_insert(xs[e][1], cs[e][1], v0, c0, v1, c1);
+    }
+    s_v[0][wave][lane] = v0;
+    s_v[1][wave][lane] = v1;
+    s_c[0][wave][lane] = c0;
+    s_c[1][wave][lane] = c1;
+    __syncthreads();
+    const int64_t flat = (int64_t)b * nq + i;
+    double qq_exact = 0.0;
+    if (wave == 0 && live) {
+        for (int w = 1; w < kFsWaves; ++w) {
+            top2_insert(s_v[0][w][lane], s_c[0][w][lane], v0, c0, v1, c1);
+            top2_insert(s_v[1][w][lane], s_c[1][w][lane], v0, c0, v1, c1);
+        }
+        float rmax2 = s_rmax[0];
+        for (int w = 1; w < kFsWaves; ++w) rmax2 = fmaxf(rmax2, s_rmax[w]);
+        // margins and decisions of nn_finalize_kernel, K = k_out = 1
+        const float qq = -2.f * qnh[flat];
+        const float scale = sqrtf(qq) * sqrtf(rmax2) + 0.5f * rmax2;
+        const float delta = err_rel * scale;
+        bool sure = true;
+        if (!(v0 > kAbsent)) {
+            if (v0 != v0) sure = false;
+        } else {
+            if (c0 < 0) sure = false;
+            if (v1 != v1) sure = false;
+            if (v1 > kAbsent && !(v0 - v1 > delta)) sure = false;
+        }
+        qq_exact = qq64[flat];
+        if (sure) {
+            const float err = delta + 2.4e-7f * qq;
+            const bool have = v0 > kAbsent && c0 >= 0;
+            float d = __builtin_inff();
+            if (have) {
+                d = qq - 2.f * v0;
+                if (!(d >= 10002.f * err))              // a close match: the filter score cannot give 1e-4 relative
+                    d = (float)exact_d2(q + (int64_t)b * C * nq + i, r + (int64_t)b * C * nr + c0, C, nq, nr, qq_exact,
+                                        rr64[(int64_t)b * nr + c0]);
+            }
+            idx[flat] = have ? c0 + index_base : -1;
+            dist[flat] = d;
+        } else if (v0 > kAbsent) {
+            s_lim[lane] = v0 - delta;
+            s_state[lane] = 1;
+            s_any = 1;
+        } else {
+            s_state[lane] = 3;
+            s_any = 1;
+        }
+    }
+    __syncthreads();
+    if (!s_any) return;                                         // uniform over the workgroup
+    // contenders of the queries inside the margin, from the registers: every stream's best that reaches the
+    // limit; a stream whose runner-up reaches it too may hide more
+    if (s_state[lane] == 1) {
+        const float lim = s_lim[lane];
+#pragma unroll
+        for (int e = 0; e < kFsParts; ++e) {
+            if (wave + kFsWaves * e >= nparts) break;
+            if (xs[e][0] >= lim) {
+                const int slot = atomicAdd(&s_ncand[lane], 1);
+                if (slot < kFsCand) s_cand[lane][slot] = cs[e][0];
+                else s_hidden[lane] = 1;
+            }
+            if (xs[e][1] > kAbsent && xs[e][1] >= lim) s_hidden[lane] = 1;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && s_state[lane] == 1) {
+        const int nc = s_ncand[lane] < kFsCand ? s_ncand[lane] : kFsCand;
+        bool hidden = s_hidden[lane] != 0 || nc < 1;
+        for (int e = 0; e < nc; ++e) hidden |= s_cand[lane][e] < 0;
+        s_state[lane] = hidden ? 3 : 2;
+    }
+    __syncthreads();
+    {
+        const int ql = tid >> 4, slot = tid & 15;               // 16 threads per query, one contender each
+        const int64_t qi = (int64_t)blockIdx.x * 64 + ql;
+        if (s_state[ql] == 2 && slot < kFsCand && slot < s_ncand[ql]) {
+            const int j = s_cand[ql][slot];
+            s_cd[ql][slot] = exact_d2(q + (int64_t)b * C * nq + qi, r + (int64_t)b * C * nr + j, C, nq, nr,
+                                      qq64[(int64_t)b * nq + qi], rr64[(int64_t)b * nr + j]);
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+        if (s_state[lane] == 2) {
+            double best_d = __builtin_inf();
+            int best_j = 0x7fffffff;
+            for (int e = 0; e < s_ncand[lane]; ++e) {
+                const double d = s_cd[lane][e];
+                const int j = s_cand[lane][e];
+                if (d < best_d || (d == best_d && j < best_j)) {
+                    best_d = d;
+                    best_j = j;
+                }
+            }
+            idx[flat] = best_j + index_base;
+            dist[flat] = (float)best_d;
+            atomicAdd(light_count, 1);                          // statistics only
+        } else if (s_state[lane] == 3) {
+            const int slot = atomicAdd(amb_count, 1);
+            amb_list[slot] = (int)flat;
+            const int pslot = atomicAdd(&pair_count[b], 1);
+            pair_list[(int64_t)b * nq + pslot] = (int)i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 4. exact float64 pass for the queued queries
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool key_less(double d0, int j0, double d1, int j1) {
@@ -2512,8 +2741,12 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     float *pval = (float *)(ws + p.off_pval);
     int *pidx = (int *)(ws + p.off_pidx);
 
+    // A call on a pair or two is a chain of short dependent launches: it takes the variants with more threads
+    // per query and fewer launches (no memset, no separate re-scoring and refinement passes).
+    const bool small = p.ktemplate == 1 && !p.split && !p.normalize && (int64_t)B * nq <= kSmallQueries &&
+                       nr <= kSmallRefs && p.nparts <= kFsWaves * kFsParts;
     // rmax and count are adjacent blocks; zero both (sizes are multiples of 256 bytes)
-    ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
+    if (!small) ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
     uint16_t *qhi = (uint16_t *)(ws + p.off_qhi), *qlo = (uint16_t *)(ws + p.off_qlo);
     uint16_t *rhi = (uint16_t *)(ws + p.off_rhi), *rlo = (uint16_t *)(ws + p.off_rlo);
     bool norms_done = false;
@@ -2529,6 +2762,10 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         norms_done = !p.split;                       // the split filter still needs its hi / lo images
     }
     if (norms_done) {
+    } else if (small) {
+        const unsigned nbq = ispa::blocks_for(nq, 64), nbr = ispa::blocks_for(nr, 64);
+        hipLaunchKernelGGL((nn_norms_small_kernel<T>), dim3(nbq + nbr, B), dim3(64), 0, s, q, r, C, nq, nr, (int)nbq,
+                           qnh, q64, rnh, r64, rmax, (int)((p.off_list - p.off_rmax) / sizeof(int)));
     } else if (p.split) {
         const float *qf = reinterpret_cast<const float *>(q), *rf = reinterpret_cast<const float *>(r);
         hipLaunchKernelGGL(nn_split_norms_kernel, dim3(ispa::blocks_for(nq, 256), B), dim3(256), 0, s, qf, C, nq, qhi,
@@ -2643,16 +2880,24 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     ispa::timing_end(timed, s);
     if (int rc = ispa::check_launch("nn_filter")) return rc;
 
+    if (small) {
+        hipLaunchKernelGGL((nn_finalize_small_kernel<T>), dim3(ispa::blocks_for(nq, 64), B), dim3(64 * kFsWaves), 0, s,
+                           pval, pidx, p.nparts, qnh, C, nq, nr, index_base, err_rel, q, r, q64, r64, dist, idx, count,
+                           list, pcount, plist, count + 1);
+        if (int rc = ispa::check_launch("nn_finalize_small_kernel")) return rc;
+    }
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
 #define ISPA_FINALIZE(KT)                                                                                     \
     hipLaunchKernelGGL((nn_finalize_kernel<T, KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
                        nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1, llist)
-    if (p.ktemplate == 1) ISPA_FINALIZE(1);
+    if (small) {
+    } else if (p.ktemplate == 1) ISPA_FINALIZE(1);
     else if (p.ktemplate == 5) ISPA_FINALIZE(5);
     else ISPA_FINALIZE(kMaxK);
 #undef ISPA_FINALIZE
     if (int rc = ispa::check_launch("nn_finalize_kernel")) return rc;
-    if (p.ktemplate == 1) {
+    if (small) {
+    } else if (p.ktemplate == 1) {
         const int64_t waves = (int64_t)B * nq < 4096 ? (int64_t)B * nq : 4096;
         hipLaunchKernelGGL((nn_rescore_top1_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval, pidx,
                            p.nparts, q, r, q64, r64, C, nq, nr, index_base, count + 1, llist, dist, idx);
@@ -2682,7 +2927,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         if (int rc = ispa::check_launch("nn_exact_top1_kernel")) return rc;
     }
     const int64_t total_q = (int64_t)B * nq;
-    const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096);
+    const unsigned eblocks = (unsigned)(total_q < 4096 ? total_q : 4096) / (small ? 4 : 1) + (small ? 1 : 0);
     // (the split filter queues thousands of queries: throughput, not latency, so it keeps the small blocks)
     const int ethreads = nr >= 8192 && !p.split ? 1024 : 256;
     const size_t esmem = (size_t)C * sizeof(double) + ethreads * (sizeof(double) + 2 * sizeof(int));
@@ -2699,7 +2944,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
                            k, index_base, exact_vec_ok, count, list, batched ? kBatchMin : 0x7fffffff, B, pcount,
                            dist, idx);
     if (int rc = ispa::check_launch("nn_exact_kernel")) return rc;
-    {
+    if (!small) {
         static unsigned long long configured = 0;       // per instantiation, one bit per device
         if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_refine_kernel<T>), kRefineLds, &configured))
             return rc;

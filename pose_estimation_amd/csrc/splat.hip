@@ -106,6 +106,9 @@ __global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__
 // resolves its band and writes the flow rows.  No global atomics, no scratch image in HBM.
 constexpr int kBandPixels = 25088;   // 98 KiB owner band (half of a 224 x 224 map): one block per CU
 constexpr int kBandThreads = 1024;
+#ifndef DISP_BATCH
+#define DISP_BATCH 4
+#endif
 constexpr int kMaxDilateSpread = 4;          // window maximum over at most 8 x 8 anchors per pixel
 constexpr int kMaxBandLds = 150 * 1024;      // bytes of dynamic LDS a band kernel may ask for
 
@@ -209,7 +212,12 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
     const CropXform cx = make_crop(c);
     const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
-    constexpr int kBatch = 4;
+    // Batches of kBatch points per thread in three phases, so that the point loads of a batch and then its
+    // depth gathers are all in flight together: (1) project, crop, band membership -> texel index (0 for a
+    // point that cannot write into this band, whose texel is discarded); (2) the gathers, unconditional;
+    // (3) visibility and the LDS update.  Only a point that can write into this band is kept, so each
+    // point is depth-tested by one band's block.
+    constexpr int kBatch = DISP_BATCH;
     for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
         double px[kBatch], py[kBatch], pz[kBatch];
 #pragma unroll
@@ -220,34 +228,52 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             py[e] = pts[3 * j + 1];
             pz[e] = pts[3 * j + 2];
         }
+        bool cand[kBatch];
+        int64_t texel_at[kBatch];
+        int iu_[kBatch], iv_[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
-            if (i >= n) continue;
             double u, v, z;
             project_point(P1, px[e], py[e], pz[e], u, v, z);
-            // crop and band membership first: only a point that can write into this band pays for
-            // the depth gather (each point is then gathered by one band's block, not by both)
+            pz[e] = z;
             double uc = u, vc = v;
-            if (!crop_apply(cx, tall, 1, uc, vc)) continue;
-            int iu, iv;
-            if (!to_int(uc, iu) || !to_int(vc, iv)) continue;
-            const int tag = (int)i + 1;
+            bool ok = i < n && crop_apply(cx, tall, 1, uc, vc);
+            int iu = 0, iv = 0;
+            ok = ok && to_int(uc, iu) && to_int(vc, iv);
             if (DILATE) {
-                int ry, cx;
-                if (!slice_anchor(iv, spread, side, ry) || !slice_anchor(iu, spread, side, cx)) continue;
+                int ry = 0, ax = 0;
+                ok = ok && slice_anchor(iv, spread, side, ry) && slice_anchor(iu, spread, side, ax);
                 const int lr = ry - (row0 - (w - 1));
-                if (lr < 0 || ry >= row1) continue;
-                if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
-                atomicMax(&owner[lr * pw + cx + w - 1], tag);
+                ok = ok && lr >= 0 && ry < row1;
+                iv_[e] = lr * pw + ax + w - 1;
+            } else {
+                int y0, y1;
+                py_slice(iv, spread, side, y0, y1);
+                ok = ok && max(y0, row0) < min(y1, row1);
+                iu_[e] = iu;
+                iv_[e] = iv;
+            }
+            bool gate;
+            const int64_t at = depth_gate_index(u, v, W, ylim, xlim, gate);
+            cand[e] = ok && gate;
+            texel_at[e] = cand[e] ? at : 0;
+        }
+        float texel[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) texel[e] = d[texel_at[e]];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            if (!depth_decide_a(cand[e], pz[e], texel[e], relax)) continue;
+            const int tag = (int)(base + (int64_t)e * kBandThreads + threadIdx.x) + 1;
+            if (DILATE) {
+                atomicMax(&owner[iv_[e]], tag);
             } else {
                 int y0, y1, x0, x1;
-                py_slice(iv, spread, side, y0, y1);
+                py_slice(iv_[e], spread, side, y0, y1);
                 y0 = max(y0, row0);
                 y1 = min(y1, row1);
-                if (y0 >= y1) continue;
-                if (!depth_test<ISPA_VIS_A>(u, v, z, d, H, W, ylim, xlim, relax)) continue;
-                py_slice(iu, spread, side, x0, x1);
+                py_slice(iu_[e], spread, side, x0, x1);
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
             }

@@ -630,6 +630,43 @@ def test_nn_nchw_layout_and_one_based(pea):
     assert np.array_equal(xy, okp.ind2coord(ind, 56))
 
 
+def test_nn_single_pair_path_matches_batch_path(pea):
+    """A call on up to 16384 queries takes kernels built for latency (more threads per query, fused
+    re-scoring and refinement); larger batches take the throughput kernels.  Both must return the same
+    bits: one awkward pair (duplicates, near ties, close matches, a self match) alone and as five copies."""
+    import torch
+    rs = np.random.RandomState(123)
+    q = _unit(rs, (1, 128, 4096))
+    r = _unit(rs, (1, 128, 4096))
+    r[0, :, 3000] = r[0, :, 17]                       # duplicate references: lowest index wins
+    r[0, :, 100:140] = r[0, :, 99:100]                # a run of identical references
+    q[0, :, 5] = r[0, :, 17]                          # exact self matches (distance 0)
+    q[0, :, 6] = r[0, :, 120]
+    base = r[0, :, 500].copy()
+    for t in range(501, 520):                         # references one float32 ulp apart
+        r[0, :, t] = base
+        r[0, t % 128, t] = np.nextafter(base[t % 128], np.float32(2.0))
+    q[0, :, 7] = base
+    close = rs.permutation(4096)[:1500]               # close matches: refined distances
+    q[0, :, 1000:2500] = r[0, :, close] .T + 1e-3 * rs.randn(128, 1500).astype(np.float32)
+    for bf16 in (False, True):
+        st1 = _nn_check(pea, q, r, 1, bf16=bf16)
+        assert st1["exact_path_queries"] >= 3
+        if bf16:
+            qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+            rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
+        else:
+            qd, rd = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+        d1, i1, s1 = pea.correspondence.dense_nn(qd, rd, 1, return_stats=True)
+        d5, i5, s5 = pea.correspondence.dense_nn(qd.expand(5, -1, -1).contiguous(), rd.expand(5, -1, -1).contiguous(), 1,
+                                                 return_stats=True)
+        for c in range(5):
+            assert torch.equal(i5[c], i1[0])
+            assert torch.equal(d5[c].view(torch.int32), d1[0].view(torch.int32))
+        assert s5["full_rescans"] == 5 * s1["full_rescans"]
+        assert s5["candidate_rescores"] == 5 * s1["candidate_rescores"]
+
+
 def test_nn_full_pair_64x64x128(pea):
     rs = np.random.RandomState(2)
     q = _unit(rs, (1, 128, 64, 64))
