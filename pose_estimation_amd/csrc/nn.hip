@@ -331,6 +331,7 @@ struct TopList {            // K+1 best scores, descending, each with its code
             v[0] = fmaxf(xs, v[0]);
         }
     }
+    __device__ __forceinline__ void flush() {}
     __device__ __forceinline__ float value(int s) const { return v[s]; }
     __device__ __forceinline__ int code(int s) const { return v[s] > kAbsent ? c[s] : -1; }
 };
@@ -407,10 +408,73 @@ struct TagTop1 {
         for (int step = 0; step < 4; ++step) push4_step(step, x, tag0, off);
     }
     __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
+    __device__ __forceinline__ void flush() {}
     __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
     __device__ __forceinline__ int code(int s) const {
         return (s == 0 && a > kAbsent) ? half * 16 + (int)(__float_as_uint(a) & 15u) : -1;
     }
+};
+
+// Top-k for the bfloat16 filter without a branch per score.  TopList above gates its 24-operation insert
+// with a wave ballot; along a stream of a few thousand scores some lane of the wave has a candidate at every
+// second score, so the wave pays for the insert most of the time and the branch keeps the vector work
+// from overlapping with the MFMAs.  Here every score is inserted, unconditionally, into a list of VALUES
+// only (one v_med3 per slot): the low kTagBits mantissa bits of a score are replaced by its position inside
+// an epoch of kEpoch half-steps (half-step within the epoch, accumulator register), so a value carries its
+// own code and no code array has to be shifted.  At the end of an epoch the few entries of the epoch's list
+// that still matter are merged, with their codes, into the stream's running list (the gated insert, at most
+// K + 1 times per epoch), and the epoch list starts empty again.  The perturbation (below 2^-(23 - kTagBits)
+// relative) is part of the margin the finalize pass tests.
+constexpr int kEpoch = 8, kTagBits = 7;                   // 8 half-steps x 16 registers = 128 positions
+#ifndef ISPA_TOPK_GATE
+#define ISPA_TOPK_GATE 0
+#endif
+template <int K, bool GATED>
+struct TagTopK {
+    float v[K + 1];                                       // this epoch's best, tagged, descending
+    TopList<K> run;                                       // best of the finished epochs, with codes
+    int tag_base, cur;
+    unsigned keep;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) v[s] = kNegInf;
+    }
+    __device__ __forceinline__ void init() {
+        clear();
+        run.init();
+        tag_base = 0;
+        cur = 0;
+        keep = ~((1u << kTagBits) - 1u);
+        // the mask lives in a vector register: v_and_or_b32 may read one scalar operand, and that is the tag
+        asm volatile("" : "+v"(keep));
+    }
+    // merges the epoch whose first half-step is `first` into the running list
+    __device__ __forceinline__ void commit(int first) {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) {
+            if (__builtin_amdgcn_ballot_w64(v[s] > run.v[K]) == 0) break;   // sorted: the rest is smaller still
+            const int tag = (int)(__float_as_uint(v[s]) & ((1u << kTagBits) - 1u));
+            run.begin_half(first + (tag >> 4));
+            run.push(v[s], tag & 15);
+        }
+        clear();
+    }
+    __device__ __forceinline__ void begin_half(int id) {
+        if ((id & (kEpoch - 1)) == 0) commit(id - kEpoch);
+        cur = id;
+        tag_base = (id & (kEpoch - 1)) << 4;
+    }
+    __device__ __forceinline__ void end_half() {}
+    __device__ __forceinline__ void push(float x, int reg) {
+        const float t = __uint_as_float((__float_as_uint(x) & keep) | (unsigned)(tag_base + reg));
+        if (GATED && __builtin_amdgcn_ballot_w64(t > v[K]) == 0) return;
+#pragma unroll
+        for (int s = K; s > 0; --s) asm("v_med3_f32 %0, %1, %2, %3" : "=v"(v[s]) : "v"(t), "v"(v[s - 1]), "v"(v[s]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(v[0]) : "v"(t), "v"(v[0]));
+    }
+    __device__ __forceinline__ void flush() { commit(cur & ~(kEpoch - 1)); }
+    __device__ __forceinline__ float value(int s) const { return run.value(s); }
+    __device__ __forceinline__ int code(int s) const { return run.code(s); }
 };
 
 template <int K, bool TAGGED>
@@ -419,6 +483,15 @@ struct ListFor {
 };
 template <>
 struct ListFor<1, true> {
+    typedef TagTop1 type;
+};
+// list of the bfloat16 filter: tagged for every k
+template <int K, int KS>
+struct BfListFor {
+    typedef TagTopK<K, (ISPA_TOPK_GATE == 1 && KS > 8) || ISPA_TOPK_GATE == 2> type;
+};
+template <int KS>
+struct BfListFor<1, KS> {
     typedef TagTop1 type;
 };
 
@@ -1007,7 +1080,7 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    typename ListFor<K, true>::type best[2];
+    typename BfListFor<K, KS>::type best[2];
     best[0].init();
     best[1].init();
 
@@ -1107,6 +1180,7 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) best[qi].push(acc_b[qi][reg], reg);
             best[qi].end_half();
+            best[qi].flush();
         }
     }
 
@@ -1687,7 +1761,8 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ qnh,
                                                           const int *__restrict__ rmaxbits, int C, int64_t nq,
                                                           int64_t nr, int k_out, int index_base,
-                                                          float err_rel, const T *__restrict__ q,
+                                                          float err_rel, float tag_rel,
+                                                          const T *__restrict__ q,
                                                           const T *__restrict__ r,
                                                           const double *__restrict__ qq64,
                                                           const double *__restrict__ rr64,
@@ -1759,7 +1834,11 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
     const float qq = -2.f * qnh[(int64_t)b * nq + i];
     const float rmax2 = __int_as_float(rmaxbits[b]);
     const float scale = sqrtf(qq) * sqrtf(rmax2) + 0.5f * rmax2;
-    const float delta = err_rel * scale;
+    // ... plus what the position tag in the low mantissa bits hides: a share tag_rel of the score's own
+    // magnitude, which for the scores that matter is well below `scale`.  delta_of(x) bounds the error of
+    // the difference of a score x and any score in [x - delta_of(x), x] (and, the bound growing much
+    // slower than the score falls, nothing further below x can overtake it either).
+    auto delta_of = [&](float x) { return err_rel * scale + tag_rel * fabsf(x); };
     bool sure = true;
 #pragma unroll
     for (int s = 0; s < K; ++s) {
@@ -1770,7 +1849,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         }
         if (c[s] < 0) sure = false;                // cannot happen for distinct scores; be safe
         if (v[s + 1] != v[s + 1]) sure = false;
-        if (v[s + 1] > kAbsent && !(v[s] - v[s + 1] > delta)) sure = false;
+        if (v[s + 1] > kAbsent && !(v[s] - v[s + 1] > delta_of(fmaxf(fabsf(v[s]), fabsf(v[s + 1]))))) sure = false;
     }
     if (sure) {
         // Distance of a kept neighbour.  The filter score s carries an error of at most delta / 2 (delta
@@ -1779,7 +1858,6 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         // that is provably under 1e-4 d, i.e. qq - 2 s >= 10002 err, it is returned; otherwise (close
         // matches: the cancellation in |q|^2 + |r|^2 - 2 q.r eats the digits) the entry is marked and
         // nn_refine_kernel recomputes the distance as the float64 pass computes it.
-        const float err = delta + 2.4e-7f * qq;
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             if (s >= k_out) break;
@@ -1790,6 +1868,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
             if (have) {
                 j = c[s];
                 d = qq - 2.f * v[s];
+                const float err = delta_of(v[s]) + 2.4e-7f * qq;
                 if (!(d >= 10002.f * err)) d = __uint_as_float(kRefineMark);   // nn_refine_kernel recomputes it
             }
             idx[o] = have ? j + index_base : -1;
@@ -1803,7 +1882,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         // contenders are known by index and re-scoring just those in float64 settles the query.  A
         // stream whose runner-up is also in range may hide contenders, and then the query goes to
         // the full float64 pass.
-        const float lim = v[0] - delta;
+        const float lim = v[0] - delta_of(v[0]);
         int cand[8];
         int nc = 0;
         bool hidden = false;
@@ -1833,7 +1912,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
         // own last kept score reaches lim.  If no stream does, the contenders are the kept entries
         // >= lim of all streams, known by index: they are re-scored in float64 (the oracle's channel
         // order) and the k smallest (distance, index) kept.
-        const float lim = v[k_out - 1] - delta;
+        const float lim = v[k_out - 1] - delta_of(v[k_out - 1]);
         bool hidden = false;
 #pragma unroll
         for (int s = 0; s < K; ++s)
@@ -2149,7 +2228,8 @@ __device__ __forceinline__ void top2_insert(float x, int code, float &v0, int &c
 template <typename T>
 __global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
     const float *__restrict__ part_val, const int *__restrict__ part_idx, int nparts, const float *__restrict__ qnh,
-    int C, int64_t nq, int64_t nr, int index_base, float err_rel, const T *__restrict__ q, const T *__restrict__ r,
+    int C, int64_t nq, int64_t nr, int index_base, float err_rel, float tag_rel, const T *__restrict__ q,
+    const T *__restrict__ r,
     const double *__restrict__ qq64, const double *__restrict__ rr64, float *__restrict__ dist,
     int *__restrict__ idx, int *__restrict__ amb_count, int *__restrict__ amb_list, int *__restrict__ pair_count,
     int *__restrict__ pair_list, int *__restrict__ light_count) {
@@ -2217,18 +2297,18 @@ __global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
         // margins and decisions of nn_finalize_kernel, K = k_out = 1
         const float qq = -2.f * qnh[flat];
         const float scale = sqrtf(qq) * sqrtf(rmax2) + 0.5f * rmax2;
-        const float delta = err_rel * scale;
+        auto delta_of = [&](float x) { return err_rel * scale + tag_rel * fabsf(x); };
         bool sure = true;
         if (!(v0 > kAbsent)) {
             if (v0 != v0) sure = false;
         } else {
             if (c0 < 0) sure = false;
             if (v1 != v1) sure = false;
-            if (v1 > kAbsent && !(v0 - v1 > delta)) sure = false;
+            if (v1 > kAbsent && !(v0 - v1 > delta_of(fmaxf(fabsf(v0), fabsf(v1))))) sure = false;
         }
         qq_exact = qq64[flat];
         if (sure) {
-            const float err = delta + 2.4e-7f * qq;
+            const float err = delta_of(v0) + 2.4e-7f * qq;
             const bool have = v0 > kAbsent && c0 >= 0;
             float d = __builtin_inff();
             if (have) {
@@ -2240,7 +2320,7 @@ __global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
             idx[flat] = have ? c0 + index_base : -1;
             dist[flat] = d;
         } else if (v0 > kAbsent) {
-            s_lim[lane] = v0 - delta;
+            s_lim[lane] = v0 - delta_of(v0);
             s_state[lane] = 1;
             s_any = 1;
         } else {
@@ -2800,8 +2880,14 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     ISPA_REQUIRE(nblocks < (1ll << 31), "problem too large for one launch");
     const dim3 grid((unsigned)nblocks);
     const ispa::TimingSlot timed = ispa::timing_begin(s);
-    float err_rel;
+    // Rounding model handed to the finalize pass: two scores a, b are ordered for certain when they differ by
+    // more than err_rel * (|q| max|r| + max|r|^2 / 2) + tag_rel * max(|a|, |b|).  tag_rel covers the mantissa
+    // bits a filter replaces by a position tag (two scores, 1.25 safety, and 0.1 % so that the bound also
+    // holds for every score within the bound below a).
+    float err_rel, tag_rel = 0.f;
     const float u = 5.9604645e-8f;   // 2^-24
+    const float kTag4 = 2.f * 1.25f * 1.001f * 1.9073486e-6f;     // 4 tagged bits: < 2^-19 of the score
+    const float kTag7 = 2.f * 1.25f * 1.001f * 1.5258789e-5f;     // kTagBits = 7: < 2^-16
     if (p.split) {
         // per score: three MFMAs per 32 channels at 2 ulp each (same model as below), what the split
         // drops (at most 3.1 * 2^-16 |q||r|), the 4 tagged mantissa bits; two scores, 1.25 safety
@@ -2824,7 +2910,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         // the last place of the largest magnitude involved.  (C/16 + 1) such steps, two scores
         // compared, 1.25 safety.  tests/test_gpu_parity.py measures the real error against this.
         err_rel = 2.f * 1.25f * 2.f * (float)(C / 16 + 1) * 2.f * u;
-        if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
+        tag_rel = p.ktemplate == 1 ? kTag4 : kTag7;
         const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
         int rc;
         if (p.t16) {
@@ -2845,7 +2931,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         // v_mfma_f32_32x32x2_f32 is a k-ordered float32 fma chain: C+1 roundings of at most
         // u * (|q||r| + |r|^2/2) each; two scores compared, 1.25 safety.
         err_rel = 2.f * 1.25f * (float)(C + 2) * u;
-        if (p.ktemplate == 1) err_rel += 2.f * 1.25f * 1.9073486e-6f;   // 4 tagged mantissa bits: < 2^-19
+        if (p.ktemplate == 1) tag_rel = kTag4;
         const int elem = (int)sizeof(T);
         const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
                            ((uintptr_t)r % (4 * elem) == 0);
@@ -2882,14 +2968,14 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
     if (small) {
         hipLaunchKernelGGL((nn_finalize_small_kernel<T>), dim3(ispa::blocks_for(nq, 64), B), dim3(64 * kFsWaves), 0, s,
-                           pval, pidx, p.nparts, qnh, C, nq, nr, index_base, err_rel, q, r, q64, r64, dist, idx, count,
+                           pval, pidx, p.nparts, qnh, C, nq, nr, index_base, err_rel, tag_rel, q, r, q64, r64, dist, idx, count,
                            list, pcount, plist, count + 1);
         if (int rc = ispa::check_launch("nn_finalize_small_kernel")) return rc;
     }
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
 #define ISPA_FINALIZE(KT)                                                                                     \
     hipLaunchKernelGGL((nn_finalize_kernel<T, KT>), fgrid, dim3(256), 0, s, pval, pidx, p.nparts, qnh, rmax, C, nq, \
-                       nr, k, index_base, err_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1, llist)
+                       nr, k, index_base, err_rel, tag_rel, q, r, q64, r64, dist, idx, count, list, pcount, plist, count + 1, llist)
     if (small) {
     } else if (p.ktemplate == 1) ISPA_FINALIZE(1);
     else if (p.ktemplate == 5) ISPA_FINALIZE(5);

@@ -718,8 +718,8 @@ def test_nn_bf16_shapes_and_error_model(pea):
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
         qr, rr = cnative.round_bf16(q), cnative.round_bf16(r)
-        # k = 1 runs the tagged 16x16x32 kernel, k = 5 the untagged 32x32x16 kernel
-        for k, tagged in ((1, True), (5, False)):
+        # k = 1 runs the 16x16x32 kernel (4 tagged mantissa bits), k = 5 the 32x32x16 kernel (7 tagged bits)
+        for k, tag_bits in ((1, 4), (5, 7)):
             dist, ind = pea.correspondence.dense_nn(qd, rd, k)
             for i in range(2):
                 _, want_d = cnative.nn_exact(qr[i], rr[i], k, 1)
@@ -727,7 +727,7 @@ def test_nn_bf16_shapes_and_error_model(pea):
                 rmax2 = (rr[i].astype(np.float64) ** 2).sum(0).max()
                 scale = qn * np.sqrt(rmax2) + 0.5 * rmax2
                 bound = 2.0 * 9 * 2 * 2.0 ** -24 * scale      # the library's per-score MFMA model, no safety
-                tag = 2.0 ** -19 * scale if tagged else 0.0   # 4 tagged mantissa bits
+                tag = 2.0 ** (tag_bits - 23) * scale           # the tag replaces the low mantissa bits
                 err = np.abs(dist[i].cpu().numpy().astype(np.float64) - want_d) / 2.0
                 # the distance also carries the float32 rounding of |q|^2 and of the final subtraction
                 slack = 2.0 ** -23 * (qn ** 2 + scale)
