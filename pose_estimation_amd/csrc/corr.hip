@@ -281,41 +281,45 @@ __global__ __launch_bounds__(256) void corr_acmm_kernel(const float *__restrict_
 // writes the column sums of squares of its rows to a partial buffer; a second kernel adds the
 // partials in a fixed order (deterministic), normalises and applies the pooled mask.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kCT = 128;   // tile edge
 constexpr int kCK = 16;    // channels per LDS stage
 
 // Operands: maps already at the grid's size (resample2_kernel below brings them there in one launch for
 // both maps).  Resampling inside this loader was measured and dropped: in an all-pairs product every
 // operand element is staged by 7 tiles at the reference's 28 x 28 grid, so the 4-tap gather was done 7
 // times over (83 us against 30 us + one 9 us resampling launch).
+// WT = 32 x 32 MFMA tiles per wave and direction: the 2 x 2 waves of a block cover a (64 WT)^2 tile.  WT = 2
+// for large grids; WT = 1 at the reference's 28 x 28 grid, where 784 cells are 6.1 tiles of 128 (a quarter
+// of a 7 x 7 tile grid would multiply zeros) and 392 blocks are a round and a half on 256 CUs.
+template <int WT>
 __global__ __launch_bounds__(256) void corr_acmm_gemm_kernel(const float *__restrict__ f1r,
                                                              const float *__restrict__ f2r, int C, int cells,
                                                              float *__restrict__ out,
                                                              float *__restrict__ colsq /* (B, 2*ptiles, cells) */) {
-    __shared__ __attribute__((aligned(16))) float As[kCK][kCT];   // f1 tile: rows p
-    __shared__ __attribute__((aligned(16))) float Bs[kCK][kCT];   // f2 tile: columns yx
+    constexpr int kT = 64 * WT;                                   // tile edge of the block
+    __shared__ __attribute__((aligned(16))) float As[kCK][kT];    // f1 tile: rows p
+    __shared__ __attribute__((aligned(16))) float Bs[kCK][kT];    // f2 tile: columns yx
     const int b = blockIdx.z;
-    const int p0 = blockIdx.y * kCT, x0 = blockIdx.x * kCT;
+    const int p0 = blockIdx.y * kT, x0 = blockIdx.x * kT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const float *a = f1r + (int64_t)b * C * cells;
     const float *bb = f2r + (int64_t)b * C * cells;
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int c0 = 0; c0 < C; c0 += kCK) {
         __syncthreads();
-        // 16 rows x 128 columns per tile = 512 groups of 4 floats, 2 per thread; cells % 4 == 0 is
+        // 16 rows x kT columns per tile in groups of 4 floats, WT per thread; cells % 4 == 0 is
         // checked on the host, so a group is entirely inside or outside the map
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < WT; ++e) {
             const int g = threadIdx.x + 256 * e;
-            const int row = g >> 5, col = (g & 31) * 4;
+            const int row = g / (kT / 4), col = (g % (kT / 4)) * 4;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
             if (c0 + row < C) {
                 if (p0 + col < cells) va = *reinterpret_cast<const float4 *>(a + (int64_t)(c0 + row) * cells + p0 + col);
@@ -327,25 +331,30 @@ __global__ __launch_bounds__(256) void corr_acmm_gemm_kernel(const float *__rest
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kCK; kk += 2) {
-            const float a0 = As[kk + h][wr * 64 + l31], a1 = As[kk + h][wr * 64 + 32 + l31];
-            const float b0 = Bs[kk + h][wc * 64 + l31], b1 = Bs[kk + h][wc * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[WT], bv[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                av[i] = As[kk + h][wr * 32 * WT + 32 * i + l31];
+                bv[i] = Bs[kk + h][wc * 32 * WT + 32 * i + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
-    // this lane owns column x0 + wc*64 + j*32 + l31 and rows p0 + wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*h
+    // this lane owns column x0 + wc*32*WT + j*32 + l31 and rows p0 + wr*32*WT + i*32 + (r&3) + 8*(r>>2) + 4*h
     float *o = out + (int64_t)b * cells * cells;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = x0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < WT; ++j) {
+        const int col = x0 + wc * 32 * WT + j * 32 + l31;
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = p0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = p0 + wr * 32 * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = fmaxf(acc[i][j][r], 0.f);
                 if (row < cells && col < cells) {
                     o[(int64_t)row * cells + col] = v;
@@ -376,8 +385,19 @@ __global__ __launch_bounds__(256) void corr_acmm_scale_kernel(float *__restrict_
             const int yy = 2 * y + dy, xx = 2 * x + dx;
             if (yy < H && xx < W) mv = fmaxf(mv, m[yy * W + xx]);
         }
+    // rows blockIdx.y, blockIdx.y + gridDim.y, ...: four loads in flight at a time
     float *o = out + (int64_t)b * cells * cells + col;
-    for (int p = blockIdx.y; p < cells; p += gridDim.y) o[(int64_t)p * cells] = o[(int64_t)p * cells] / norm * mv;
+    const int64_t step = (int64_t)gridDim.y * cells;
+    int p = blockIdx.y;
+    for (; p + 3 * (int)gridDim.y < cells; p += 4 * gridDim.y) {
+        float *o0 = o + (int64_t)p * cells;
+        const float v0 = o0[0], v1 = o0[step], v2 = o0[2 * step], v3 = o0[3 * step];
+        o0[0] = v0 / norm * mv;
+        o0[step] = v1 / norm * mv;
+        o0[2 * step] = v2 / norm * mv;
+        o0[3 * step] = v3 / norm * mv;
+    }
+    for (; p < cells; p += gridDim.y) o[(int64_t)p * cells] = o[(int64_t)p * cells] / norm * mv;
 }
 
 __global__ __launch_bounds__(256) void l2norm_kernel(const float *__restrict__ x, int C, int64_t hw,
@@ -460,7 +480,9 @@ extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float 
     if (cells % 4 == 0) {
         // one launch brings both maps to the grid's size (skipped when they are there already), then the
         // MFMA product and the deterministic column normalisation; workspace = resampled maps + partials
-        const int ptiles = (cells + kCT - 1) / kCT;
+        const bool small_tiles = cells <= 2048;             // 64 x 64 block tiles: less padding, more blocks
+        const int tile = small_tiles ? 64 : 128;
+        const int ptiles = (cells + tile - 1) / tile;
         const float *f1r = f1, *f2r = f2;
         float *colsq = workspace;
         if (H != grid || W != grid) {
@@ -473,12 +495,16 @@ extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float 
             f2r = r2;
         }
         const ispa::TimingSlot timed = ispa::timing_begin(s);
-        hipLaunchKernelGGL(corr_acmm_gemm_kernel, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells, out,
-                           colsq);
+        if (small_tiles)
+            hipLaunchKernelGGL(corr_acmm_gemm_kernel<1>, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells,
+                               out, colsq);
+        else
+            hipLaunchKernelGGL(corr_acmm_gemm_kernel<2>, dim3(ptiles, ptiles, B), dim3(256), 0, s, f1r, f2r, C, cells,
+                               out, colsq);
         ispa::timing_end(timed, s);
         if (int rc = ispa::check_launch("corr_acmm_gemm_kernel")) return rc;
-        hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, (cells + 7) / 8, B), dim3(256), 0, s, out, colsq,
-                           2 * ptiles, mask, grid, H, W);
+        hipLaunchKernelGGL(corr_acmm_scale_kernel, dim3((cells + 255) / 256, (cells + 27) / 28, B), dim3(256), 0, s, out,
+                           colsq, 2 * ptiles, mask, grid, H, W);
         return ispa::check_launch("corr_acmm_scale_kernel");
     }
     hipLaunchKernelGGL(corr_acmm_kernel, dim3((cells + 63) / 64, B), dim3(256), 0, s, f1, f2, mask, C, grid, rs, out);
