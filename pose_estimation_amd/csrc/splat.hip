@@ -62,6 +62,19 @@ __device__ __forceinline__ int window_owner(const int *img, int pw, int ly, int 
     return o;
 }
 
+// spread 2 (the reference's 4 x 4 blocks): all 16 anchors read before the first comparison
+__device__ __forceinline__ int window_owner4(const int *img, int pw, int ly, int x) {
+    int t[16];
+#pragma unroll
+    for (int dr = 0; dr < 4; ++dr)
+#pragma unroll
+        for (int dc = 0; dc < 4; ++dc) t[4 * dr + dc] = img[(ly + 3 - dr) * pw + x + 3 - dc];
+    int o = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o = max(o, t[e]);
+    return o;
+}
+
 __global__ __launch_bounds__(kThreads) void flow_owner_kernel(const double *__restrict__ uv1,
                                                               const uint8_t *__restrict__ truth, int64_t n,
                                                               int spread, int side,
@@ -174,7 +187,8 @@ __global__ __launch_bounds__(kBandThreads) void flow_band_kernel(const double *_
     __syncthreads();
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     for (int p = threadIdx.x; p < npix; p += kBandThreads) {
-        const int o = DILATE ? window_owner(owner, pw, p / side, p % side, w) : owner[p];
+        const int o = DILATE ? (w == 4 ? window_owner4(owner, pw, p / side, p % side) : window_owner(owner, pw, p / side, p % side, w))
+                             : owner[p];
         double2 val = make_double2(0.0, 0.0);
         if (o > 0) {
             const int64_t i = o - 1;
@@ -239,14 +253,17 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             pz[e] = z;
             double uc = u, vc = v;
             bool ok = i < n && crop_apply(cx, tall, 1, uc, vc);
-            int iu = 0, iv = 0;
-            ok = ok && to_int(uc, iu) && to_int(vc, iv);
+            // A point inside the crop has remapped coordinates in [0, side] (strictly inside the box, times a
+            // positive ratio, plus a non-negative pad), so the conversions cannot overflow, the Python slice
+            // [c - r : c + r] cannot wrap from above, and slice_anchor() reduces to: empty for c < r (the lower
+            // bound wraps past the upper one), anchor c - r otherwise.  Lanes with ok == false carry garbage
+            // that is never used (the float -> int conversion saturates, it does not trap).
+            const int iu = (int)uc, iv = (int)vc;
             if (DILATE) {
-                int ry = 0, ax = 0;
-                ok = ok && slice_anchor(iv, spread, side, ry) && slice_anchor(iu, spread, side, ax);
-                const int lr = ry - (row0 - (w - 1));
-                ok = ok && lr >= 0 && ry < row1;
-                iv_[e] = lr * pw + ax + w - 1;
+                ok = ok && iu >= spread && iv >= spread && iu < side + spread && iv < side + spread;
+                const int lr = iv - spread - (row0 - (w - 1));
+                ok = ok && lr >= 0 && iv - spread < row1;
+                iv_[e] = lr * pw + iu - spread + w - 1;
             } else {
                 int y0, y1;
                 py_slice(iv, spread, side, y0, y1);
@@ -254,8 +271,11 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
                 iu_[e] = iu;
                 iv_[e] = iv;
             }
-            bool gate;
-            const int64_t at = depth_gate_index(u, v, W, ylim, xlim, gate);
+            // depth gate (pt2render.py:47-49) on the rounded coordinates as integers: u and v are integer-valued
+            // (or not finite / huge, which saturate or become 0 and fail the gate like the float comparison)
+            const int gx = (int)u, gy = (int)v;
+            const bool gate = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
+            const int64_t at = gate ? (int64_t)gy * W + gx : 0;
             cand[e] = ok && gate;
             texel_at[e] = cand[e] ? at : 0;
         }
@@ -282,7 +302,8 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     __syncthreads();
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     for (int p = threadIdx.x; p < npix; p += kBandThreads) {
-        const int o = DILATE ? window_owner(owner, pw, p / side, p % side, w) : owner[p];
+        const int o = DILATE ? (w == 4 ? window_owner4(owner, pw, p / side, p % side) : window_owner(owner, pw, p / side, p % side, w))
+                             : owner[p];
         double2 val = make_double2(0.0, 0.0);
         if (o > 0) {
             const int64_t i = o - 1;
