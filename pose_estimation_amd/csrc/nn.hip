@@ -55,6 +55,45 @@ __device__ __forceinline__ int xcd_order(int bid, int nblocks) {
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (bid >> 3);
 }
 
+// What one workgroup of a filter kernel works on.  Grid = pairs x reference splits x query tiles, walked in the
+// XCD-friendly order of xcd_order(): the query tiles of one (pair, split), which stream the same references,
+// sit next to each other.
+struct FilterWork {
+    int split, b;            // reference split, image pair
+    int64_t q0;              // first query column of the tile
+    int64_t rbeg, rend;      // reference range of the split
+    int nchunks;             // chunks of `chunk_refs` references in that range
+};
+__device__ __forceinline__ FilterWork filter_work(int n_qtiles, int nsplit, int64_t refs_per_split, int64_t nr,
+                                                  int tile_queries, int chunk_refs) {
+    int bid = xcd_order(blockIdx.x, gridDim.x);
+    FilterWork w;
+    w.q0 = (int64_t)(bid % n_qtiles) * tile_queries;
+    bid /= n_qtiles;
+    w.split = bid % nsplit;
+    w.b = bid / nsplit;
+    w.rbeg = (int64_t)w.split * refs_per_split;
+    w.rend = min(w.rbeg + refs_per_split, nr);
+    w.nchunks = (int)((w.rend - w.rbeg + chunk_refs - 1) / chunk_refs);
+    return w;
+}
+
+// The partial list of one query stream goes to part_val / part_idx (pairs, streams, SLOTS, queries); finalize
+// merges the streams.  `to_ref` turns a list code into a reference index.
+template <int SLOTS, typename List, typename ToRef>
+__device__ __forceinline__ void store_partial(const List &best, ToRef to_ref, float *__restrict__ part_val,
+                                              int *__restrict__ part_idx, int b, int nparts, int part, int64_t nq,
+                                              int64_t qcol) {
+    if (qcol >= nq) return;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int code = best.code(s);
+        const int64_t o = (((int64_t)b * nparts + part) * SLOTS + s) * nq + qcol;
+        part_val[o] = best.value(s);
+        part_idx[o] = code >= 0 ? to_ref(code) : -1;
+    }
+}
+
 __device__ __forceinline__ float load_as_float(const float *p) { return *p; }
 __device__ __forceinline__ float load_as_float(const uint16_t *p) {
     return __uint_as_float(((uint32_t)*p) << 16);
@@ -555,11 +594,8 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     __shared__ float Nh[2][kTR];
 
     // block -> (pair, split, query tile)
-    int bid = xcd_order(blockIdx.x, gridDim.x);
-    const int qt = bid % n_qtiles;
-    bid /= n_qtiles;
-    const int split = bid % nsplit;
-    const int b = bid / nsplit;
+    const FilterWork fw = filter_work(n_qtiles, nsplit, refs_per_split, nr, kTQ, kTR);
+    const int split = fw.split, b = fw.b;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -569,10 +605,8 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     const T *qb = q + (int64_t)b * C * nq;
     const T *rb = r + (int64_t)b * C * nr;
     const float *nhb = rnh + (int64_t)b * nr;
-    const int64_t q0 = (int64_t)qt * kTQ;
-    const int64_t rbeg = (int64_t)split * refs_per_split;
-    const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+    const int64_t q0 = fw.q0, rbeg = fw.rbeg, rend = fw.rend;
+    const int nchunks = fw.nchunks;
     const int nk = (C + kKC - 1) / kKC;
     const int total = nchunks * nk;
 
@@ -701,23 +735,14 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
     // one partial stream per (split, wr, h); finalize merges them
     const int nparts = nsplit * kSubStreams;
     const int part = split * kSubStreams + wr * 2 + h;
+    // code = (chunk * 2 + row tile) * 16 + accumulator register
+    auto to_ref = [&](int code) {
+        const int reg = code & 15, ri = (code >> 4) & 1;
+        return (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    };
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
-        if (qcol >= nq) continue;
-#pragma unroll
-        for (int s = 0; s <= K; ++s) {
-            const int code = best[qi].code(s);
-            int ref = -1;
-            if (code >= 0) {
-                const int reg = code & 15, ri = (code >> 4) & 1;
-                ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-            }
-            const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
-            part_val[o] = best[qi].value(s);
-            part_idx[o] = ref;
-        }
-    }
+    for (int qi = 0; qi < 2; ++qi)
+        store_partial<K + 1>(best[qi], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qi * 32 + l31);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,11 +787,8 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     __shared__ __attribute__((aligned(16))) float Rs[kRing][kKC][kTR];
     __shared__ __attribute__((aligned(16))) float Nh[2][kTR];
 
-    int bid = xcd_order(blockIdx.x, gridDim.x);
-    const int qt = bid % n_qtiles;
-    bid /= n_qtiles;
-    const int split = bid % nsplit;
-    const int b = bid / nsplit;
+    const FilterWork fw = filter_work(n_qtiles, nsplit, refs_per_split, nr, kTQ, kTR);
+    const int split = fw.split, b = fw.b;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -776,10 +798,8 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
     const float *qb = q + (int64_t)b * C * nq;
     const float *rb = r + (int64_t)b * C * nr;
     const float *nhb = rnh + (int64_t)b * nr;
-    const int64_t q0 = (int64_t)qt * kTQ;
-    const int64_t rbeg = (int64_t)split * refs_per_split;
-    const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kTR - 1) / kTR);
+    const int64_t q0 = fw.q0, rbeg = fw.rbeg, rend = fw.rend;
+    const int nchunks = fw.nchunks;
     const int total = nchunks * NKS;
 
     // reference stage `st` (chunk st / NKS, channels 16 (st % NKS) ..) -> ring slot; one wave
@@ -894,23 +914,14 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
 
     const int nparts = nsplit * kSubStreams;
     const int part = split * kSubStreams + wr * 2 + h;
+    // code = (chunk * 2 + row tile) * 16 + accumulator register
+    auto to_ref = [&](int code) {
+        const int reg = code & 15, ri = (code >> 4) & 1;
+        return (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    };
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
-        if (qcol >= nq) continue;
-#pragma unroll
-        for (int s = 0; s <= K; ++s) {
-            const int code = best[qi].code(s);
-            int ref = -1;
-            if (code >= 0) {
-                const int reg = code & 15, ri = (code >> 4) & 1;
-                ref = (int)(rbeg + (int64_t)(code >> 5) * kTR + wr * 64 + ri * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-            }
-            const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
-            part_val[o] = best[qi].value(s);
-            part_idx[o] = ref;
-        }
-    }
+    for (int qi = 0; qi < 2; ++qi)
+        store_partial<K + 1>(best[qi], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qi * 32 + l31);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -998,11 +1009,8 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     char *rbuf = lds;                                   // ring of 3 chunk images
     float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);   // ring of 3 x kBR floats
 
-    int bid = xcd_order(blockIdx.x, gridDim.x);
-    const int qt = bid % n_qtiles;
-    bid /= n_qtiles;
-    const int split = bid % nsplit;
-    const int b = bid / nsplit;
+    const FilterWork fw = filter_work(n_qtiles, nsplit, refs_per_split, nr, kBQ, kBR);
+    const int split = fw.split, b = fw.b;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = tid >> 6;
@@ -1014,10 +1022,8 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     const uint16_t *qb = q + (int64_t)b * C * nq;
     const uint16_t *rb = r + (int64_t)b * C * nr;
     const float *nhb = rnh + (int64_t)b * nr;
-    const int64_t q0 = (int64_t)qt * kBQ;
-    const int64_t rbeg = (int64_t)split * refs_per_split;
-    const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
+    const int64_t q0 = fw.q0, rbeg = fw.rbeg, rend = fw.rend;
+    const int nchunks = fw.nchunks;
 
     // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
 #pragma unroll
@@ -1187,23 +1193,14 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     // one partial stream per (split, lane half); finalize merges them
     const int nparts = nsplit * kBSubStreams;
     const int part = split * kBSubStreams + h;
+    // code = half-step * 16 + accumulator register
+    auto to_ref = [&](int code) {
+        const int reg = code & 15;
+        return (int)(rbeg + (int64_t)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    };
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const int64_t qcol = q0 + wq * 64 + qi * 32 + l31;
-        if (qcol >= nq) continue;
-#pragma unroll
-        for (int s = 0; s <= K; ++s) {
-            const int code = best[qi].code(s);
-            int ref = -1;
-            if (code >= 0) {                             // code = half-step * 16 + accumulator register
-                const int reg = code & 15;
-                ref = (int)(rbeg + (int64_t)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-            }
-            const int64_t o = (((int64_t)b * nparts + part) * (K + 1) + s) * nq + qcol;
-            part_val[o] = best[qi].value(s);
-            part_idx[o] = ref;
-        }
-    }
+    for (int qi = 0; qi < 2; ++qi)
+        store_partial<K + 1>(best[qi], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qi * 32 + l31);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1234,11 +1231,8 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     char *rbuf = lds;
     float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);
 
-    int bid = xcd_order(blockIdx.x, gridDim.x);
-    const int qt0 = bid % n_qtiles;
-    bid /= n_qtiles;
-    const int split = bid % nsplit;
-    const int b = bid / nsplit;
+    const FilterWork fw = filter_work(n_qtiles, nsplit, refs_per_split, nr, kBQ, kBR);
+    const int split = fw.split, b = fw.b;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = tid >> 6;
@@ -1251,10 +1245,8 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     const uint16_t *qb = q + (int64_t)b * C * nq;
     const uint16_t *rb = r + (int64_t)b * C * nr;
     const float *nhb = rnh + (int64_t)b * nr;
-    const int64_t q0 = (int64_t)qt0 * kBQ;
-    const int64_t rbeg = (int64_t)split * refs_per_split;
-    const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
+    const int64_t q0 = fw.q0, rbeg = fw.rbeg, rend = fw.rend;
+    const int nchunks = fw.nchunks;
 
     // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
 #pragma unroll
@@ -1437,23 +1429,14 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     // one partial stream per (split, lane >> 4); finalize merges them
     const int nparts = nsplit * kT16SubStreams;
     const int part = split * kT16SubStreams + g;
+    // code = chunk * 16 + (half-step * 8 + tile * 4 + accumulator register)
+    auto to_ref = [&](int code) {
+        const int tag = code & 15;
+        return (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
+    };
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        const int64_t qcol = q0 + wq * 64 + qt * 16 + l15;
-        if (qcol >= nq) continue;
-#pragma unroll
-        for (int sl = 0; sl <= 1; ++sl) {
-            const int code = best[qt].code(sl);
-            int ref = -1;
-            if (code >= 0) {                             // code = chunk * 16 + (half-step * 8 + tile * 4 + reg)
-                const int tag = code & 15;
-                ref = (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
-            }
-            const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
-            part_val[o] = best[qt].value(sl);
-            part_idx[o] = ref;
-        }
-    }
+    for (int qt = 0; qt < 4; ++qt)
+        store_partial<2>(best[qt], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qt * 16 + l15);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1539,11 +1522,8 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
     char *ring = lds;
     float *nhbuf = reinterpret_cast<float *>(lds + 2 * kSlot);
 
-    int bid = xcd_order(blockIdx.x, gridDim.x);
-    const int qt0 = bid % n_qtiles;
-    bid /= n_qtiles;
-    const int split = bid % nsplit;
-    const int b = bid / nsplit;
+    const FilterWork fw = filter_work(n_qtiles, nsplit, refs_per_split, nr, kSQ, kBR);
+    const int split = fw.split, b = fw.b;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = tid >> 6;
@@ -1553,10 +1533,8 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
 
     const int64_t qoff = (int64_t)b * C * nq, roff = (int64_t)b * C * nr;
     const float *nhb = rnh + (int64_t)b * nr;
-    const int64_t q0 = (int64_t)qt0 * kSQ;
-    const int64_t rbeg = (int64_t)split * refs_per_split;
-    const int64_t rend = min(rbeg + refs_per_split, nr);
-    const int nchunks = (int)((rend - rbeg + kBR - 1) / kBR);
+    const int64_t q0 = fw.q0, rbeg = fw.rbeg, rend = fw.rend;
+    const int nchunks = fw.nchunks;
 
     // ---- query fragments: stage the hi image, read, then the lo image, read ----------------------
     bf16x8 bq[2][2][KS32];                              // [hi/lo][query tile][k-step]
@@ -1733,23 +1711,14 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
 
     const int nparts = nsplit * kT16SubStreams;
     const int part = split * kT16SubStreams + g;
+    // code = chunk * 16 + (half-step * 8 + tile * 4 + accumulator register)
+    auto to_ref = [&](int code) {
+        const int tag = code & 15;
+        return (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
+    };
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int64_t qcol = q0 + wq * 32 + qt * 16 + l15;
-        if (qcol >= nq) continue;
-#pragma unroll
-        for (int sl = 0; sl <= 1; ++sl) {
-            const int code = best[qt].code(sl);
-            int ref = -1;
-            if (code >= 0) {
-                const int tag = code & 15;
-                ref = (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
-            }
-            const int64_t o = (((int64_t)b * nparts + part) * 2 + sl) * nq + qcol;
-            part_val[o] = best[qt].value(sl);
-            part_idx[o] = ref;
-        }
-    }
+    for (int qt = 0; qt < 2; ++qt)
+        store_partial<2>(best[qt], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 32 + qt * 16 + l15);
 }
 
 // ---------------------------------------------------------------------------------------------
