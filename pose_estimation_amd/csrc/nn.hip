@@ -102,12 +102,23 @@ __device__ __forceinline__ float load_as_float(const uint16_t *p) {
 // Squared distance of one (query column, reference column) pair in the CPU oracle's arithmetic:
 // (qq + rr) - 2 dot, dot accumulated over channels in increasing order in float64 (a product of two
 // float32 values is exact in float64), qq and rr from the norms kernel, accumulated the same way.  Two
-// identical columns give exactly 0.  16 channels of loads are in flight at a time.
+// identical columns give exactly 0.  32 channels of loads are in flight at a time (every one of them is a
+// different 64-byte sector, a microsecond or more away when the maps do not fit into L2), then 16.
 template <typename T>
 __device__ __forceinline__ double exact_d2(const T *__restrict__ qcol, const T *__restrict__ rcol, int C, int64_t nq,
                                            int64_t nr, double qq, double rr) {
     double dot = 0.0;
     int c0 = 0;
+    for (; c0 + 32 <= C; c0 += 32) {
+        float qv[32], rv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            qv[u] = load_as_float(qcol + (int64_t)(c0 + u) * nq);
+            rv[u] = load_as_float(rcol + (int64_t)(c0 + u) * nr);
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) dot = fma((double)qv[u], (double)rv[u], dot);
+    }
     for (; c0 + 16 <= C; c0 += 16) {
         float qv[16], rv[16];
 #pragma unroll
@@ -2953,12 +2964,13 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     if (int rc = ispa::check_launch("nn_finalize_kernel")) return rc;
     if (small) {
     } else if (p.ktemplate == 1) {
-        const int64_t waves = (int64_t)B * nq < 4096 ? (int64_t)B * nq : 4096;
+        // a wave per queued query, as many as the chip holds at once (256 CUs x 32 waves) for large batches
+        const int64_t waves = (int64_t)B * nq < 8192 ? (int64_t)B * nq : 8192;
         hipLaunchKernelGGL((nn_rescore_top1_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval, pidx,
                            p.nparts, q, r, q64, r64, C, nq, nr, index_base, count + 1, llist, dist, idx);
         if (int rc = ispa::check_launch("nn_rescore_top1_kernel")) return rc;
     } else {
-        const int64_t waves = (int64_t)B * nq < 4096 ? (int64_t)B * nq : 4096;
+        const int64_t waves = (int64_t)B * nq < 8192 ? (int64_t)B * nq : 8192;
 #define ISPA_RESCORE_TOPK(KT)                                                                                  \
     hipLaunchKernelGGL((nn_rescore_topk_kernel<T, KT>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pval,  \
                        pidx, p.nparts, q, r, q64, r64, C, nq, nr, k, index_base, count + 1, llist, dist, idx)
