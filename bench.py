@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--poses", type=int, default=3600)
     ap.add_argument("--maps", type=int, default=256)
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--model", choices=["chair", "cube"], default="chair",
+                    help="geometry workloads: the synthetic model the points come from. chair: area-weighted surface "
+                         "samples of a box-built chair mesh (the reference samples CAD mesh surfaces, "
+                         "run_proj.py:15-22); cube: points uniform in a solid cube (no surface: the worst case for "
+                         "anything that relies on neighbouring points landing on neighbouring pixels)")
     ap.add_argument("--unfused", action="store_true",
                     help="disparity workload through project_prune x2 + flow_splat instead of the fused kernel")
     ap.add_argument("--filter", choices=["native", "split"], default="native",
@@ -145,24 +150,37 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         return None, None
 
 
+def synthetic_model(kind, n, seed):
+    """(n, 3) float64 model points inside the [-0.4, 0.4] cube of the reference's normalised CAD models."""
+    if kind == "cube":
+        return np.random.RandomState(seed).uniform(-0.4, 0.4, (n, 3))
+    from pose_estimation_amd import run_proj
+    return run_proj.sample_surface(*run_proj.chair_mesh(), n, seed=seed)
+
+
+MODEL_NAMES = {"chair": "surface samples of a box-built chair mesh", "cube": "points uniform in a solid cube"}
+
+
 def run_geometry(args, torch, dist, world, rank, dev):
     """Workloads 'project' and 'disparity' (inputs resident in HBM, one GPU's share per rank)."""
     import pose_estimation_amd as pea
     from pose_estimation_amd import _abi, _device as dv, sharding
     n = args.points
     rs = np.random.RandomState(100 + rank)
-    pts_np = rs.uniform(-0.4, 0.4, (n, 3))
+    pts_np = synthetic_model(args.model, n, 100 + rank)
     if args.workload == "zbuffer" and not args.unfused:
         args.morton = True                           # the tiled pass bins chunks of consecutive points per tile
     if args.morton:                                  # one-time model preprocessing, outside the timed region
         pts_np = pts_np[pea.run_proj.spatial_order(pts_np)]
     pts = torch.from_numpy(pts_np).to(dev)
     st = lambda: dv.stream_ptr()
+    sharded = False                                  # config 4 over several ranks: the total work is fixed
     crop_one = torch.tensor([[100, 400, 300, 700]], dtype=torch.int32, device=dev)
     if args.workload == "project":
         P = args.poses
         poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
         if world > 1 and P == len(poses):                # config 4: the pose grid sharded over the ranks
+            sharded = True
             lo, hi = sharding.shard_range(len(poses), rank, world)
             poses = poses[lo:hi]
             P = hi - lo
@@ -211,6 +229,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
         P = args.poses
         poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
         if world > 1 and P == len(poses):                # config 4: the pose grid sharded over the ranks
+            sharded = True
             lo, hi = sharding.shard_range(len(poses), rank, world)
             poses = poses[lo:hi]
             P = hi - lo
@@ -323,9 +342,10 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
         "value": round(units * world * args.steps / elapsed, 2), "unit": unit_name, "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f32" if args.workload == "corr" else "f64", "data": "synthetic",
-        "config": {"workload": workload, "points": n, "point_order": "hilbert curve (run_proj.spatial_order)" if args.morton else "as generated"},
+        "config": {"workload": workload, "points": n, "model": MODEL_NAMES[args.model],
+                   "point_order": "hilbert curve (run_proj.spatial_order)" if args.morton else "as generated"},
         "roofline": dict(roof, traffic=traffic, traffic_source=traffic_src, kernel=names[dom],
                          kernel_ms=round(per[dom], 4), work_per_launch=alg_bytes[dom],
                          all_kernels_ms={f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}),
@@ -362,7 +382,7 @@ def cpu_baseline_geometry(args):
                           f"5-D broadcast"}
     n = args.points
     rs = np.random.RandomState(0)
-    pts = rs.uniform(-0.4, 0.4, (n, 3))
+    pts = synthetic_model(args.model, n, 0)
     depth = np.full((540, 960), 3.0, np.float32)
     crop = [100, 400, 300, 700]
     done, t0 = 0, time.perf_counter()

@@ -39,6 +39,13 @@ def get_keypoints(file_name, k=100000, seed=None):
     verts, faces = load_obj(file_name)
     if len(faces) == 0:
         raise ValueError(f"{file_name} holds no faces")
+    return sample_surface(verts, faces, k, seed)
+
+
+def sample_surface(verts, faces, k=100000, seed=None):
+    """k points drawn uniformly from the surface of a triangle mesh (verts (V,3), faces (F,3)): triangle by
+    area, then a uniform barycentric point."""
+    verts, faces = np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int64)
     rs = np.random.RandomState(seed)
     a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
     area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
@@ -47,6 +54,28 @@ def get_keypoints(file_name, k=100000, seed=None):
     flip = u + v > 1.0                                   # reflect into the triangle
     u[flip], v[flip] = 1.0 - u[flip], 1.0 - v[flip]
     return a[tri] + u[:, None] * (b[tri] - a[tri]) + v[:, None] * (c[tri] - a[tri])
+
+
+def box_mesh(boxes):
+    """Triangle mesh of axis-aligned boxes [(xmin, ymin, zmin, xmax, ymax, zmax), ...] -> verts (8B,3), faces (12B,3)."""
+    corner = np.array([[i, j, k] for i in (0, 1) for j in (0, 1) for k in (0, 1)], dtype=np.float64)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    verts, faces = [], []
+    for n, bx in enumerate(np.asarray(boxes, dtype=np.float64)):
+        verts.append(bx[:3] + corner * (bx[3:] - bx[:3]))
+        for q in quads:
+            faces += [[8 * n + q[0], 8 * n + q[1], 8 * n + q[2]], [8 * n + q[0], 8 * n + q[2], 8 * n + q[3]]]
+    return np.concatenate(verts), np.asarray(faces, dtype=np.int64)
+
+
+def chair_mesh():
+    """A chair-sized stand-in for a CAD model (seat, back rest, four legs, two arm rests as boxes) inside the
+    [-0.4, 0.4] cube the reference's normalised models occupy; for synthetic workloads."""
+    legs = [(x, -0.40, z, x + 0.05, -0.05, z + 0.05) for x in (-0.30, 0.25) for z in (-0.30, 0.25)]
+    return box_mesh([(-0.30, -0.05, -0.30, 0.30, 0.00, 0.30),            # seat
+                     (-0.30, 0.00, -0.30, 0.30, 0.40, -0.25),           # back rest
+                     (-0.30, 0.15, -0.25, -0.25, 0.18, 0.25),           # arm rests
+                     (0.25, 0.15, -0.25, 0.30, 0.18, 0.25)] + legs)
 
 
 def get_3d_to_2d(model_pts, params):

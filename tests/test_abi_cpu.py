@@ -112,3 +112,11 @@ def test_surface_sampler_without_trimesh(tmp_path):
     assert on.all() and pts.min() >= -1e-12 and pts[:, 2].max() <= 2 + 1e-12
     # areas: bottom / top 1 each, four sides 2 each -> a tenth of the samples on the bottom face
     assert abs(np.isclose(pts[:, 2], 0).mean() - 0.1) < 0.01
+    # box_mesh / chair_mesh (the synthetic model of the geometry benches): closed boxes inside the reference's cube
+    verts, faces = run_proj.box_mesh([(0, 0, 0, 1, 2, 3)])
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    assert faces.shape == (12, 3) and np.isclose(0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1).sum(), 22.0)
+    cv, cf = run_proj.chair_mesh()
+    assert cv.shape[0] == 8 * cf.shape[0] // 12 and np.abs(cv).max() <= 0.4
+    chair = run_proj.sample_surface(cv, cf, 5000, seed=3)
+    assert chair.shape == (5000, 3) and np.abs(chair).max() <= 0.4 + 1e-12

@@ -8,6 +8,8 @@ from pose_estimation_amd import _abi
 n, P = 100000, int(sys.argv[1]) if len(sys.argv) > 1 else 720
 rs = np.random.RandomState(100)
 pts_np = rs.uniform(-0.4, 0.4, (n, 3))
+if os.environ.get('ZB_MODEL') == 'chair':
+    pts_np = pea.run_proj.sample_surface(*pea.run_proj.chair_mesh(), n, seed=100)
 pts_np = pts_np[pea.run_proj.spatial_order(pts_np, curve=os.environ.get('ZB_CURVE', 'hilbert'))]
 pts = torch.from_numpy(pts_np).cuda()
 poses = np.array([[az, el, 0.0, 3.0] for az in range(360) for el in range(-10, 40, 5)], dtype=np.float64)
