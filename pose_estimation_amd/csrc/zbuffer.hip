@@ -339,12 +339,19 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
     // Items come off the counter in groups of kGroup consecutive ones, two groups ahead: the counter is asked
     // for the group after next while a group is worked on, so the item after the current one is always known
     // and its pose box and chunk boxes can be fetched a whole item early (under the stores of this kernel a
-    // load takes microseconds).
+    // load takes microseconds).  The last items (about kGroup per workgroup) are handed out one by one, so that
+    // no workgroup ends the launch with a whole group of expensive tiles while the others are idle: the counter
+    // counts groups, the first n_full of them kGroup items long, the rest single items.
+    const int64_t tail_items = min(total_items, (int64_t)kGroup * gridDim.x);
+    const int n_full = (int)((total_items - tail_items) / kGroup);
+    const int n_groups = n_full + (int)(total_items - (int64_t)n_full * kGroup);
+    auto group_first = [&](int g) { return g < n_full ? g * kGroup : n_full * kGroup + (g - n_full); };
+    auto group_size = [&](int g) { return g < n_full ? kGroup : 1; };
     __shared__ int ahead[2];
     if (threadIdx.x == 0) {
         cnt[0] = cnt[1] = 0;
-        ahead[0] = atomicAdd(counter, kGroup);
-        ahead[1] = atomicAdd(counter, kGroup);
+        ahead[0] = atomicAdd(counter, 1);
+        ahead[1] = atomicAdd(counter, 1);
     }
     __syncthreads();
     int group = ahead[0], group_next = ahead[1], in_group = 0;
@@ -360,12 +367,13 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
             pre[r] = nchunks > 0 ? box[(int64_t)pp * nchunks + min(r * kZThreads + (int)threadIdx.x, nchunks - 1)]
                                  : make_short4(0, 0, 0, 0);
     };
-    prefetch(group);
+    prefetch(group < n_groups ? group_first(group) : 0);
     for (;;) {
-        const int item = group + in_group;
-        if (item >= total_items) break;               // groups only grow: nothing is left
-        if (threadIdx.x == 0 && in_group == 0) fetched = atomicAdd(counter, kGroup);   // the group after next
-        const int item_next = in_group + 1 < kGroup ? item + 1 : group_next;
+        if (group >= n_groups) break;                 // group numbers only grow: nothing is left
+        const int item = group_first(group) + in_group;
+        if (threadIdx.x == 0 && in_group == 0) fetched = atomicAdd(counter, 1);   // the group after next
+        const int item_next = in_group + 1 < group_size(group) ? item + 1
+                                                               : (group_next < n_groups ? group_first(group_next) : 0);
         const int p = item / ntiles, tl = item - p * ntiles;
         const int tx0 = (tl % tiles_x) * kTileW, ty0 = (tl / tiles_x) * kTileH;
         const int tx1 = min(tx0 + kTileW, W) - 1, ty1 = min(ty0 + kTileH, H) - 1;  // inclusive
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
         }
         ZB_T(any ? 4 : 9);
         __syncthreads();                              // the tile has been read: the next item may reset it
-        if (++in_group == kGroup) {
+        if (++in_group == group_size(group)) {
             if (threadIdx.x == 0) ahead[0] = fetched;
             __syncthreads();
             group = group_next;
