@@ -354,6 +354,8 @@ struct TopList {            // K+1 best scores, descending, each with its code
     }
     __device__ __forceinline__ void begin_half(int id) { base = id * 16; }
     __device__ __forceinline__ void end_half() {}
+    template <typename Acc>
+    __device__ __forceinline__ void end_half(const Acc &) {}
     __device__ __forceinline__ void push(float x, int reg) {
         const int code = base + reg;
         if (K == 1) {
@@ -458,6 +460,8 @@ struct TagTop1 {
         for (int step = 0; step < 4; ++step) push4_step(step, x, tag0, off);
     }
     __device__ __forceinline__ void end_half() { half = a != a_before ? cur : half; }
+    template <typename Acc>
+    __device__ __forceinline__ void end_half(const Acc &) { end_half(); }
     __device__ __forceinline__ void flush() {}
     __device__ __forceinline__ float value(int s) const { return s == 0 ? a : b; }
     __device__ __forceinline__ int code(int s) const {
@@ -468,20 +472,26 @@ struct TagTop1 {
 // Top-k for the bfloat16 filter without a branch per score.  TopList above gates its 24-operation insert
 // with a wave ballot; along a stream of a few thousand scores some lane of the wave has a candidate at every
 // second score, so the wave pays for the insert most of the time and the branch keeps the vector work
-// from overlapping with the MFMAs.  Here every score is inserted, unconditionally, into a list of VALUES
-// only (one v_med3 per slot): the low kTagBits mantissa bits of a score are replaced by its position inside
-// an epoch of kEpoch half-steps (half-step within the epoch, accumulator register), so a value carries its
-// own code and no code array has to be shifted.  At the end of an epoch the few entries of the epoch's list
-// that still matter are merged, with their codes, into the stream's running list (the gated insert, at most
-// K + 1 times per epoch), and the epoch list starts empty again.  The perturbation (below 2^-(23 - kTagBits)
-// relative) is part of the margin the finalize pass tests.
+// from overlapping with the MFMAs.  Here the low kTagBits mantissa bits of a score are replaced by its
+// position inside an epoch of kEpoch half-steps (half-step within the epoch, accumulator register), so a
+// value carries its own code and lists of VALUES only (one v_med3 per slot) do the work:
+//   per score    the best three of the current half-step's 16 scores (g1 >= g2 >= g3): 4 operations;
+//   per half-step  if no lane's g3 beats what its lists already hold as (K+1)-th best, no lane can have more
+//                than two scores of this half-step in its final list, and g1, g2 are inserted into the epoch
+//                list (6 operations each); otherwise (the first few hundred scores of a stream, rarely later)
+//                all 16 scores are inserted;
+//   per epoch    the entries of the epoch list that still matter are merged, with their codes, into the
+//                stream's running list (the gated insert, at most K + 1 times), and the epoch list starts
+//                empty again.
+// The perturbation (below 2^-(23 - kTagBits) relative) is part of the margin the finalize pass tests.
 constexpr int kEpoch = 8, kTagBits = 7;                   // 8 half-steps x 16 registers = 128 positions
-#ifndef ISPA_TOPK_GATE
-#define ISPA_TOPK_GATE 0
+#ifndef ISPA_TOPK_GROUP
+#define ISPA_TOPK_GROUP 1
 #endif
-template <int K, bool GATED>
+template <int K>
 struct TagTopK {
     float v[K + 1];                                       // this epoch's best, tagged, descending
+    float g1, g2, g3;                                     // this half-step's best three, tagged
     TopList<K> run;                                       // best of the finished epochs, with codes
     int tag_base, cur;
     unsigned keep;
@@ -494,6 +504,7 @@ struct TagTopK {
         run.init();
         tag_base = 0;
         cur = 0;
+        g1 = g2 = g3 = kNegInf;
         keep = ~((1u << kTagBits) - 1u);
         // the mask lives in a vector register: v_and_or_b32 may read one scalar operand, and that is the tag
         asm volatile("" : "+v"(keep));
@@ -513,14 +524,38 @@ struct TagTopK {
         if ((id & (kEpoch - 1)) == 0) commit(id - kEpoch);
         cur = id;
         tag_base = (id & (kEpoch - 1)) << 4;
+        g1 = g2 = g3 = kNegInf;
     }
-    __device__ __forceinline__ void end_half() {}
-    __device__ __forceinline__ void push(float x, int reg) {
-        const float t = __uint_as_float((__float_as_uint(x) & keep) | (unsigned)(tag_base + reg));
-        if (GATED && __builtin_amdgcn_ballot_w64(t > v[K]) == 0) return;
+    __device__ __forceinline__ float tagged(float x, int reg) const {
+        return __uint_as_float((__float_as_uint(x) & keep) | (unsigned)(tag_base + reg));
+    }
+    __device__ __forceinline__ void insert(float t) {
 #pragma unroll
         for (int s = K; s > 0; --s) asm("v_med3_f32 %0, %1, %2, %3" : "=v"(v[s]) : "v"(t), "v"(v[s - 1]), "v"(v[s]));
         asm("v_max_f32 %0, %1, %2" : "=v"(v[0]) : "v"(t), "v"(v[0]));
+    }
+    __device__ __forceinline__ void push(float x, int reg) {
+        const float t = tagged(x, reg);
+        if (ISPA_TOPK_GROUP) {
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(g3) : "v"(t), "v"(g2), "v"(g3));
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(g2) : "v"(t), "v"(g1), "v"(g2));
+            asm("v_max_f32 %0, %1, %2" : "=v"(g1) : "v"(t), "v"(g1));
+        } else {
+            insert(t);
+        }
+    }
+    // `scores`: the 16 accumulator registers pushed since begin_half
+    template <typename Acc>
+    __device__ __forceinline__ void end_half(const Acc &scores) {
+        if (!ISPA_TOPK_GROUP) return;
+        const float have = fmaxf(v[K], run.v[K]);         // nothing at or below it can end up in the list
+        if (__builtin_amdgcn_ballot_w64(g3 > have) == 0) {
+            insert(g1);
+            insert(g2);
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) insert(tagged(scores[reg], reg));
+        }
     }
     __device__ __forceinline__ void flush() { commit(cur & ~(kEpoch - 1)); }
     __device__ __forceinline__ float value(int s) const { return run.value(s); }
@@ -538,7 +573,7 @@ struct ListFor<1, true> {
 // list of the bfloat16 filter: tagged for every k
 template <int K, int KS>
 struct BfListFor {
-    typedef TagTopK<K, (ISPA_TOPK_GATE == 1 && KS > 8) || ISPA_TOPK_GATE == 2> type;
+    typedef TagTopK<K> type;
 };
 template <int KS>
 struct BfListFor<1, KS> {
@@ -1005,14 +1040,20 @@ constexpr int bf16_filter_lds_bytes() {
     return stream > qimage ? stream : qimage;
 }
 
-template <int KS, int K>
-__global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kernel(
+// QT = 32-query tiles per wave.  QT = 2: 4 waves of 64 queries (two workgroups per CU up to 128 channels, one
+// above).  QT = 1: 8 waves of 32 queries for more than 128 channels, where the LDS images leave room for one
+// workgroup only: two waves per SIMD, so that one wave's LDS reads and list updates run under the other's MFMAs
+// (with one wave per SIMD nothing hides them).
+template <int KS, int K, int QT>
+__global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filter_bf16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx) {
     constexpr int C = 16 * KS;
     constexpr int kRBuf = C * kRStride;                 // one reference chunk image
-    constexpr int kSeg = KS / 2;                        // 16-byte segments per thread per chunk
+    constexpr int kNT = 512 / QT;                       // threads
+    constexpr int kSeg = KS * QT / 4;                   // 1 KiB pieces of a chunk image per wave
+    static_assert(QT == 2 || KS % 4 == 0, "8 waves share 2 KS pieces evenly only if KS is a multiple of 4");
     // up to 128 channels two blocks share a CU; above that the query fragments alone take 128
     // registers and the LDS images 144 KiB, so one block owns the CU
     static_assert(KS % 2 == 0 && KS <= 16, "C must be a multiple of 32, at most 256");
@@ -1038,8 +1079,8 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
 
     // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
 #pragma unroll
-    for (int e = 0; e < 2 * KS; ++e) {                   // C rows x 32 segments of 8 queries
-        const int seg = tid + kBThreads * e;
+    for (int e = 0; e < KS * QT; ++e) {                  // C rows x 32 segments of 8 queries
+        const int seg = tid + kNT * e;
         const int row = seg >> 5, col = (seg & 31) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)row * nq + q0 + col);
@@ -1080,12 +1121,12 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     };
     auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
     __syncthreads();
-    bf16x8 bq[2][KS];
+    bf16x8 bq[QT][KS];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            bq[qi][ks] = tr_frag(lds + (ks * 16 + tr_row) * kQStride + (wq * 64 + qi * 32 + tr_col) * 2, kQStride);
+            bq[qi][ks] = tr_frag(lds + (ks * 16 + tr_row) * kQStride + (wq * 32 * QT + qi * 32 + tr_col) * 2, kQStride);
     __syncthreads();                                     // query image no longer needed
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
@@ -1097,20 +1138,23 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    typename BfListFor<K, KS>::type best[2];
-    best[0].init();
-    best[1].init();
+    typename BfListFor<K, KS>::type best[QT];
+#pragma unroll
+    for (int qi = 0; qi < QT; ++qi) best[qi].init();
 
     // Each chunk is two half-steps (its reference rows 0-31 and 32-63).  The MFMAs of one half-step
     // are interleaved, in a pinned program order, with the top-list update of the previous
     // half-step's accumulators, so the matrix pipe and the vector ALU work at the same time; the
     // transposed LDS reads run two k-steps ahead of their MFMAs.
-    f32x16 acc_a[2], acc_b[2];
+    f32x16 acc_a[QT], acc_b[QT];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) acc_b[0][reg] = acc_b[1][reg] = kNegInf;   // nothing pending yet
-    // opaque to the optimiser: otherwise it peels the first iteration to fold these constants and
-    // the pinned MFMA / vector interleave of the steady-state loop is lost
-    asm volatile("" : "+v"(acc_b[0]), "+v"(acc_b[1]));
+    for (int qi = 0; qi < QT; ++qi) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc_b[qi][reg] = kNegInf;               // nothing pending yet
+        // opaque to the optimiser: otherwise it peels the first iteration to fold these constants and
+        // the pinned MFMA / vector interleave of the steady-state loop is lost
+        asm volatile("" : "+v"(acc_b[qi]));
+    }
 
     auto load_init = [&](const float *nh, int ri) {
         f32x16 v;
@@ -1132,30 +1176,27 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     // prev_half).  a0 / a1 hold the fragments of k-steps 0 and 1 on entry and those of the next
     // half-step (`next_img`, `next_ri`) on exit.
     auto half_step = [&](const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 &a0, bf16x8 &a1,
-                         const f32x16 &init, f32x16 (&now)[2], const f32x16 (&prev)[2], int prev_half) {
-        best[0].begin_half(prev_half);
-        best[1].begin_half(prev_half);
+                         const f32x16 &init, f32x16 (&now)[QT], const f32x16 (&prev)[QT], int prev_half) {
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) best[qi].begin_half(prev_half);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 a2 = ks + 2 < KS ? frag(rimg, ri, ks + 2) : frag(next_img, next_ri, ks + 2 - KS);
-            now[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[0][ks], ks ? now[0] : init, 0, 0, 0);
 #pragma unroll
-            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
-                if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[0][reg]));
-                else best[0].push(prev[0][reg], reg);
-            }
-            now[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[1][ks], ks ? now[1] : init, 0, 0, 0);
+            for (int qi = 0; qi < QT; ++qi) {
+                now[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[qi][ks], ks ? now[qi] : init, 0, 0, 0);
 #pragma unroll
-            for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
-                if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[1][reg]));
-                else best[1].push(prev[1][reg], reg);
+                for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
+                    if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[qi][reg]));
+                    else best[qi].push(prev[qi][reg], reg);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             a0 = a1;
             a1 = a2;
         }
-        best[0].end_half();
-        best[1].end_half();
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) best[qi].end_half(prev[qi]);
     };
 
     // chunk c lives in ring slot c % 3.  Mid-chunk c: the norm entries of chunk c+1 go to LDS, all
@@ -1192,11 +1233,11 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < QT; ++qi) {
             best[qi].begin_half(nchunks * 2 - 1);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) best[qi].push(acc_b[qi][reg], reg);
-            best[qi].end_half();
+            best[qi].end_half(acc_b[qi]);
             best[qi].flush();
         }
     }
@@ -1210,8 +1251,9 @@ __global__ __launch_bounds__(kBThreads, KS > 8 ? 1 : 2) void nn_filter_bf16_kern
         return (int)(rbeg + (int64_t)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
     };
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-        store_partial<K + 1>(best[qi], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qi * 32 + l31);
+    for (int qi = 0; qi < QT; ++qi)
+        store_partial<K + 1>(best[qi], to_ref, part_val, part_idx, b, nparts, part, nq,
+                             q0 + wq * 32 * QT + qi * 32 + l31);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2734,11 +2776,13 @@ template <int KS, int KT>
 int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                 int64_t nr, const Plan &p, float *pval, int *pidx) {
     constexpr int lds_bytes = bf16_filter_lds_bytes<KS>();
+    // more than 128 channels (one workgroup per CU): 8 waves of 32 queries where the chunk pieces divide evenly
+    constexpr int QT = (KS > 8 && KS % 4 == 0) ? 1 : 2;
     static unsigned long long configured = 0;       // per instantiation, one bit per device
-    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT>), lds_bytes,
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_kernel<KS, KT, QT>), lds_bytes,
                                          &configured))
         return rc;
-    hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
+    hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT, QT>), grid, dim3(512 / QT), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
     return ISPA_OK;
 }
