@@ -399,7 +399,10 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
                 P[k] = FROM_RENDER ? 0.0 : cams[(int64_t)p * 12 + k];
                 asm volatile("" : "+v"(P[k]));
             }
-            for (int e = threadIdx.x; e < kTileH * kTileW; e += kZThreads) tile[e] = kEmptyKey;
+            {
+                const u64x2 empty = {kEmptyKey, kEmptyKey};
+                for (int e = threadIdx.x; e < kTileH * kTileW / 2; e += kZThreads) reinterpret_cast<u64x2 *>(tile)[e] = empty;
+            }
             __syncthreads();
             ZB_T(1);
             int vbase = 0, segments = 0;
@@ -439,27 +442,39 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
         // the tile goes to HBM once (pairs of pixels: 16-byte stores of keys, 8-byte of winners / depths)
         const int64_t img = (int64_t)p * H * W;
         const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-        if (vec_ok) {
-            const int pairs = tw >> 1;                                               // W even, so tw is even
-            for (int e = threadIdx.x; e < th * pairs; e += kZThreads) {
-                const int ly = pairs == kTileW / 2 ? e >> 6 : e / pairs, lx = (e - ly * pairs) * 2;
-                const unsigned long long k0 = any ? tile[ly * kTileW + lx] : kEmptyKey;
-                const unsigned long long k1 = any ? tile[ly * kTileW + lx + 1] : kEmptyKey;
-                const int64_t o = img + (int64_t)(ty0 + ly) * W + tx0 + lx;
-                // streaming stores: the images are written once and not read here, and must not push the
-                // model's points and the box tables out of L2
-                if (packed) {
-                    const u64x2 kk = {k0, k1};
+        if (vec_ok && kZThreads % (tw >> 1) == 0) {
+            // A thread owns one pair of pixel columns and every (kZThreads / pairs)-th row: the LDS offset and the
+            // image offset advance by constants, two keys leave LDS as one 16-byte read (W is even here, so tw
+            // is; tiles are 128 or, at the right border, W % 128 pixels wide: a power of two for the usual sizes).
+            const int pairs = tw >> 1, rows_per = kZThreads / pairs;
+            const int lx = ((int)threadIdx.x % pairs) * 2, ly0 = (int)threadIdx.x / pairs;
+            const unsigned long long *src = tile + ly0 * kTileW + lx;
+            int64_t o = img + (int64_t)(ty0 + ly0) * W + tx0 + lx;
+            const int64_t o_step = (int64_t)rows_per * W;
+            const int s_step = rows_per * kTileW;
+            const bool only_packed = packed && !winner && !depth;
+            if (only_packed) {                                   // the common case, nothing else in the loop
+                const u64x2 empty = {kEmptyKey, kEmptyKey};
+                for (int ly = ly0; ly < th; ly += rows_per, src += s_step, o += o_step) {
+                    const u64x2 kk = any ? *reinterpret_cast<const u64x2 *>(src) : empty;
                     __builtin_nontemporal_store(kk, reinterpret_cast<u64x2 *>(packed + o));
                 }
-                if (winner) {
-                    const i32x2 ww = {k0 == kEmptyKey ? -1 : (int)(uint32_t)k0, k1 == kEmptyKey ? -1 : (int)(uint32_t)k1};
-                    __builtin_nontemporal_store(ww, reinterpret_cast<i32x2 *>(winner + o));
-                }
-                if (depth) {
-                    const f32x2 dd = {k0 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k0 >> 32)),
-                                      k1 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k1 >> 32))};
-                    __builtin_nontemporal_store(dd, reinterpret_cast<f32x2 *>(depth + o));
+            } else {
+                for (int ly = ly0; ly < th; ly += rows_per, src += s_step, o += o_step) {
+                    const unsigned long long k0 = any ? src[0] : kEmptyKey, k1 = any ? src[1] : kEmptyKey;
+                    if (packed) {
+                        const u64x2 kk = {k0, k1};
+                        __builtin_nontemporal_store(kk, reinterpret_cast<u64x2 *>(packed + o));
+                    }
+                    if (winner) {
+                        const i32x2 ww = {k0 == kEmptyKey ? -1 : (int)(uint32_t)k0, k1 == kEmptyKey ? -1 : (int)(uint32_t)k1};
+                        __builtin_nontemporal_store(ww, reinterpret_cast<i32x2 *>(winner + o));
+                    }
+                    if (depth) {
+                        const f32x2 dd = {k0 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k0 >> 32)),
+                                          k1 == kEmptyKey ? __builtin_inff() : __uint_as_float((uint32_t)(k1 >> 32))};
+                        __builtin_nontemporal_store(dd, reinterpret_cast<f32x2 *>(depth + o));
+                    }
                 }
             }
         } else {
