@@ -247,8 +247,10 @@ int ispa_corr_map_eccv_views(const float *f1, const float *f2, const int64_t *kn
 /* acmm_net CorrelationMapLayer.forward, correlation part
  *   classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
  * mask (B,1,H,W) f32 (max-pooled 2x2 ceil inside).  out (B, grid*grid, grid, grid) f32.
- * workspace: 2*B*C*cells + 2*B*ceil(cells/64)*cells floats, cells = grid*grid (both maps at the grid's
- * size, written by one launch, and the column partials of the normalisation). */
+ * workspace: ispa_corr_map_acmm_workspace_floats(B, C, grid) floats (both maps at the grid's size, written by
+ * one launch, and the column partials of the normalisation: 2*B*C*cells + 2*B*ceil(cells/64)*cells with
+ * cells = grid*grid in this build; ask the function, the tiling may change). */
+size_t ispa_corr_map_acmm_workspace_floats(int B, int C, int grid);
 int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
                        int W, int grid, float *out, float *workspace, void *stream);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ispa_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "ispa_corr_map_eccv": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ispa_corr_map_eccv_views": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "ispa_corr_map_acmm_workspace_floats": (_sz, [_i, _i, _i]),
     "ispa_corr_map_acmm": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ispa_extract_feature": (_i, [_p, _i, _i, _i, _i, _p, _i64, _i, _i, ctypes.c_float, _i, _p, _p]),
     "ispa_nearest_view": (_i, [_p, _i, _p, _i, _p, _p, _p]),

@@ -242,8 +242,7 @@ def correlation_map_acmm(feature1, feature2, mask, grid=28):
     if m.shape != (b, 1, h, w):
         raise ValueError(f"mask must be ({b},1,{h},{w})")
     out = dv.empty((b, grid * grid, grid, grid), torch.float32)
-    cells = grid * grid
-    ws = _workspace((2 * b * c * cells + 2 * b * ((cells + 63) // 64) * cells) * 4)
+    ws = _workspace(4 * _abi.lib.ispa_corr_map_acmm_workspace_floats(b, c, grid))
     _abi.check(_abi.lib.ispa_corr_map_acmm(dv.ptr(f1), dv.ptr(f2), dv.ptr(m), b, c, h, w, grid, dv.ptr(out),
                                            dv.ptr(ws), dv.stream_ptr()))
     return dv.back(out, as_tensor)

@@ -466,6 +466,13 @@ extern "C" int ispa_corr_map_eccv(const float *f1, const float *f2, const int64_
     return ispa_corr_map_eccv_views(f1, f2, knn, B, 1, C, H, W, K, grid, out, workspace, stream);
 }
 
+extern "C" size_t ispa_corr_map_acmm_workspace_floats(int B, int C, int grid) {
+    if (B <= 0 || C <= 0 || grid <= 0) return 0;
+    const size_t cells = (size_t)grid * grid;
+    const size_t tile = cells <= 2048 ? 64 : 128;        // the GEMM's block tile, as chosen in ispa_corr_map_acmm
+    return 2 * (size_t)B * C * cells + 2 * (size_t)B * ((cells + tile - 1) / tile) * cells;
+}
+
 extern "C" int ispa_corr_map_acmm(const float *f1, const float *f2, const float *mask, int B, int C, int H,
                                   int W, int grid, float *out, float *workspace, void *stream) {
     ISPA_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && grid > 0, "bad shape");
