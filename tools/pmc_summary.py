@@ -18,11 +18,12 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*_FETCH_SIZE"))):
     wl = os.path.basename(d)[len("pmc_"):-len("_FETCH_SIZE")]
     vals = collections.defaultdict(dict)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = glob.glob(os.path.join(src, f"pmc_{wl}_{counter}", "*", "*counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(src, f"pmc_{wl}_{counter}", "*", "*counter_collection.csv")),
+                       key=os.path.getmtime)
         if not files:
             continue
         agg, cnt = collections.defaultdict(float), collections.Counter()
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(files[-1])):       # the newest run if the directory holds several
             name = r["Kernel_Name"]
             if "(anonymous namespace)::" not in name or "at::native" in name:
                 continue

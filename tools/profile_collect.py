@@ -15,13 +15,15 @@ import subprocess
 import sys
 
 src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+if not glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    sys.exit(f"no rocprofv3 counter output under {src}/pmc_*: nothing collected, {dst} left as it is")
 for d in sorted(glob.glob(os.path.join(src, "stats_*"))):
     if not os.path.isdir(d):
         continue
     tag = os.path.basename(d)[len("stats_"):]
-    hits = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
-    if hits:
-        shutil.copy(hits[0], os.path.join(dst, f"{rnd}_stats_{tag}_kernel_stats.csv"))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if hits:                                             # the newest run if the directory holds several
+        shutil.copy(hits[-1], os.path.join(dst, f"{rnd}_stats_{tag}_kernel_stats.csv"))
     js = os.path.join(src, f"stats_{tag}.json")
     if os.path.exists(js):
         lines = [l for l in open(js).read().splitlines() if l.startswith("{")]
@@ -31,11 +33,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     name = os.path.basename(d)[len("pmc_"):]
-    hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    hits = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not hits:
         continue
     agg, cnt = collections.defaultdict(float), collections.Counter()
-    for r in csv.DictReader(open(hits[0])):
+    for r in csv.DictReader(open(hits[-1])):
         if "(anonymous namespace)::" not in r["Kernel_Name"] or "at::native" in r["Kernel_Name"]:
             continue
         key = (r["Kernel_Name"][:160], r["Counter_Name"])
