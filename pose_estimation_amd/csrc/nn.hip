@@ -566,6 +566,10 @@ template <int K, bool TAGGED>
 struct ListFor {
     typedef TopList<K> type;
 };
+template <int K>
+struct ListFor<K, true> {           // top-k: the tagged value lists (defined above for the bfloat16 filter)
+    typedef TagTopK<K> type;
+};
 template <>
 struct ListFor<1, true> {
     typedef TagTop1 type;
@@ -774,9 +778,11 @@ __global__ __launch_bounds__(kThreads, K == 1 ? 4 : 2) void nn_filter_f32_kernel
                         for (int e = 0; e < 4; ++e) best[qi].push(acc[ri][qi][reg + e], reg + e);
                     }
                 }
-                best[qi].end_half();
+                best[qi].end_half(acc[ri][qi]);
             }
     }
+    best[0].flush();
+    best[1].flush();
 
     // one partial stream per (split, wr, h); finalize merges them
     const int nparts = nsplit * kSubStreams;
@@ -953,9 +959,11 @@ __global__ __launch_bounds__(kThreads, 2) void nn_filter_f32_qreg_kernel(
                         for (int e = 0; e < 4; ++e) best[qi].push(acc[ri][qi][reg + e], reg + e);
                     }
                 }
-                best[qi].end_half();
+                best[qi].end_half(acc[ri][qi]);
             }
     }
+    best[0].flush();
+    best[1].flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
 
     const int nparts = nsplit * kSubStreams;
@@ -2955,7 +2963,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         // v_mfma_f32_32x32x2_f32 is a k-ordered float32 fma chain: C+1 roundings of at most
         // u * (|q||r| + |r|^2/2) each; two scores compared, 1.25 safety.
         err_rel = 2.f * 1.25f * (float)(C + 2) * u;
-        if (p.ktemplate == 1) tag_rel = kTag4;
+        tag_rel = p.ktemplate == 1 ? kTag4 : kTag7;      // both list types of the float32 filters are tagged
         const int elem = (int)sizeof(T);
         const int vec_ok = (nq % 4 == 0) && (nr % 4 == 0) && ((uintptr_t)q % (4 * elem) == 0) &&
                            ((uintptr_t)r % (4 * elem) == 0);
