@@ -1,0 +1,77 @@
+"""One-off randomized differential check of dense_nn against the CPU oracle (development tool, needs a GPU):
+more shapes, value ranges and near-tie structures than the seeded sweep in tests/, including large-batch cases
+that take the throughput kernels and clustered features that make top-k lists fight over close scores."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pose_estimation_amd as pea                       # noqa: E402
+from oracle import cnative                              # noqa: E402
+
+
+def check(q, r, k, mode, index_base):
+    if mode == "bf16":
+        qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
+        rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
+        dist, ind = pea.correspondence.dense_nn(qd, rd, k, index_base)
+        dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
+        q, r = cnative.round_bf16(q), cnative.round_bf16(r)
+    else:
+        dist, ind = pea.correspondence.dense_nn(q, r, k, index_base, filter="split" if mode == "split" else "native")
+    for i in range(q.shape[0]):
+        want_i, want_d = cnative.nn_exact(q[i], r[i], k, index_base)
+        if not np.array_equal(ind[i], want_i):
+            return f"index mismatch ({int(np.sum(ind[i] != want_i))} entries)"
+        fin = np.isfinite(want_d)
+        if not np.all(np.abs(dist[i] - want_d)[fin] <= 1e-4 * np.abs(want_d[fin])):
+            return "distance outside 1e-4 relative"
+    return None
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+    rs = np.random.RandomState(seed)
+    t0, cases = time.time(), 0
+    while time.time() - t0 < budget:
+        c = int(rs.choice([8, 32, 64, 96, 128, 192, 256]))
+        k = int(rs.choice([1, 1, 2, 5, 5, 8]))
+        mode = str(rs.choice(["f32", "bf16", "bf16", "split"]))
+        big = rs.rand() < 0.25
+        b = int(rs.randint(5, 9)) if big else int(rs.randint(1, 4))
+        nq = 8 * int(rs.randint(300, 520)) if big else 8 * int(rs.randint(1, 300))
+        nr = 8 * int(rs.randint(64, 700))
+        style = int(rs.randint(0, 4))
+        if style == 0:                                    # random unit vectors
+            q, r = rs.randn(b, c, nq), rs.randn(b, c, nr)
+        elif style == 1:                                  # clustered: many close scores
+            centres = rs.randn(b, c, 12)
+            r = centres[:, :, rs.randint(0, 12, nr)] + 0.05 * rs.randn(b, c, nr)
+            q = centres[:, :, rs.randint(0, 12, nq)] + 0.05 * rs.randn(b, c, nq)
+        elif style == 2:                                  # queries are noisy copies of references
+            r = rs.randn(b, c, nr)
+            q = r[:, :, rs.randint(0, nr, nq)] + 10.0 ** rs.uniform(-4, -1) * rs.randn(b, c, nq)
+        else:                                             # wide range of norms
+            r = rs.randn(b, c, nr) * rs.uniform(0.1, 8.0, (b, 1, nr))
+            q = rs.randn(b, c, nq) * rs.uniform(0.1, 8.0, (b, 1, nq))
+        q, r = q.astype(np.float32), r.astype(np.float32)
+        if style != 3:
+            q /= np.sqrt((q ** 2).sum(1, keepdims=True))
+            r /= np.sqrt((r ** 2).sum(1, keepdims=True))
+        err = check(q, r, k, mode, int(rs.randint(0, 2)))
+        cases += 1
+        if err:
+            print(f"FAIL case {cases}: {err}; c={c} k={k} mode={mode} b={b} nq={nq} nr={nr} style={style} seed={seed}",
+                  flush=True)
+            sys.exit(1)
+        if cases % 20 == 0:
+            print(f"{cases} cases ok ({time.time() - t0:.0f} s)", flush=True)
+    print(f"all {cases} cases ok")
+
+
+if __name__ == "__main__":
+    main()
