@@ -6,6 +6,12 @@ importing this module raises.
 import ctypes
 import os
 
+# torch before the library: libispa_hip.so and torch must share ONE HIP runtime (device pointers and streams pass
+# between them), and the dynamic loader keeps whichever libamdhip64.so.7 comes first.  With the library first
+# the system copy wins and torch's own bundled stack is left half replaced: the first HIP call then fails with
+# "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ISPA_HIP_LIBRARY points at another build of the same library (development builds)
 LIB_PATH = os.environ.get("ISPA_HIP_LIBRARY") or os.path.join(_HERE, "libispa_hip.so")

@@ -120,3 +120,18 @@ def test_surface_sampler_without_trimesh(tmp_path):
     assert cv.shape[0] == 8 * cf.shape[0] // 12 and np.abs(cv).max() <= 0.4
     chair = run_proj.sample_surface(cv, cf, 5000, seed=3)
     assert chair.shape == (5000, 3) and np.abs(chair).max() <= 0.4 + 1e-12
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """The library and torch must end up on the same libamdhip64 (they exchange device pointers and streams): the
+    package imports torch before it loads libispa_hip.so, so importing the package first must not bring in the
+    system copy of the runtime beside torch's."""
+    import subprocess
+    import sys
+    code = ("import pose_estimation_amd, re\n"
+            "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+            "print(len(paths), sorted(paths))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
