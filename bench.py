@@ -150,6 +150,23 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         return None, None
 
 
+def measured_stream_rates(torch, dev, nbytes=1 << 31, reps=10):
+    """(fill GB/s, copy GB/s counting read + write) of torch's own fill_ / copy_ on a 2 GiB buffer."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = []
+    for fn, moved in ((lambda: a.fill_(1), nbytes), (lambda: b.copy_(a), 2 * nbytes)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out.append(moved * reps / (time.perf_counter() - t0) / 1e9)
+    return out[0], out[1]
+
+
 def synthetic_model(kind, n, seed):
     """(n, 3) float64 model points inside the [-0.4, 0.4] cube of the reference's normalised CAD models."""
     if kind == "cube":
@@ -327,6 +344,12 @@ def run_geometry(args, torch, dist, world, rank, dev):
     achieved = alg_bytes[dom] / (per[dom] * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4)}
+    if args.workload != "corr":
+        # what this box's memory system takes when nothing but stores (fill) or loads + stores (copy) are asked of
+        # it: the practical ceiling beside the nominal 8 TB/s
+        fill, copy = measured_stream_rates(torch, dev)
+        roof.update(measured_fill_gbs=round(fill, 1), measured_copy_gbs=round(copy, 1),
+                    frac_of_fill=round(achieved / fill, 4))
     if names[dom] == "corr_acmm_gemm":                  # alg_bytes holds FLOP for this kernel
         tf = alg_bytes[dom] / (per[dom] * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
