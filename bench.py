@@ -11,7 +11,10 @@ collective in the data path) and the index/distance records are all-gathered onc
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The default run (one GPU, no flags) also carries, under `extra`, side
+measurements that are not part of `value`: the bfloat16 and split-bfloat16 filters, queries with close matches, and
+(`extra.stages`) the projection, z-buffer, disparity and correlation stages at their BASELINE sizes, each through
+the same code as `--workload <stage>`.
 """
 import argparse
 import ctypes
@@ -68,7 +71,9 @@ def parse():
                     help="torch.distributed backend; 'gloo' with ranks sharing one GPU rehearses the multi-rank "
                          "code path on a single-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the bfloat16 side measurement of the f32 run")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the side measurements of the default run (bfloat16 / split filter / close matches, and "
+                         "the projection, z-buffer, disparity and correlation stages at their BASELINE sizes)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -355,7 +360,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
     per = [float(np.mean(ms[i:cnt.value:recs])) for i in range(recs)]
     dom = int(np.argmax(per))
     if rank != 0:
-        return
+        return None
     achieved = alg_bytes[dom] / (per[dom] * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4)}
@@ -391,7 +396,31 @@ def run_geometry(args, torch, dist, world, rank, dev):
     }
     if not args.no_cpu_baseline and world == 1:
         out_json["cpu_baseline"] = cpu_baseline_geometry(args)
-    print(json.dumps(out_json))
+    return out_json
+
+
+def stage_records(args, torch, dist, dev):
+    """The other stages of the path at their BASELINE sizes, a few steps each, for the `extra.stages` block of the
+    default run (one GPU): the same measurement code as `--workload <stage>`, trimmed to the fields that say what
+    ran and how close to its roofline.  Not part of `value`."""
+    import copy
+    out = {}
+    for wl in ("project", "zbuffer", "disparity", "corr"):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.no_cpu_baseline = wl, 5, 2, True
+        a.poses, a.maps, a.points, a.model, a.unfused, a.one_launch, a.morton = 3600, 256, 100000, "chair", False, False, False
+        rec = run_geometry(a, torch, dist, 1, 0, dev)
+        roof = rec["roofline"]
+        out[wl] = {"value": rec["value"], "unit": rec["unit"], "steps": a.steps, "ms_per_step": rec["ms_per_step"],
+                   "dtype": rec["dtype"], "workload": rec["config"]["workload"],
+                   "point_order": rec["config"]["point_order"],
+                   "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms",
+                                                     "frac_of_fill", "measured_fill_gbs") if k in roof}}
+        if wl == "corr":
+            out[wl]["note"] = ("66 KB-sized problem of five dependent launches: latency-bound at the reference's "
+                               "shapes, the HBM fraction says only that no bandwidth is needed")
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline_geometry(args):
@@ -486,7 +515,9 @@ def main():
 
     dev = torch.device("cuda", torch.cuda.current_device())
     if args.workload != "nn":
-        run_geometry(args, torch, dist, world, rank, dev)
+        rec = run_geometry(args, torch, dist, world, rank, dev)
+        if rec is not None:
+            print(json.dumps(rec))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -588,6 +619,12 @@ def main():
                 "note": "queries = noisy copies of template cells: all distances re-scored in float64 (nn_refine_kernel)",
                 "kernel": "nn_filter", "kernel_ms": round(km, 4)}
             del qm, perm
+
+    default_shape = (b, g, c, args.k, args.dtype, filt) == (512, 64, 128, 1, "f32", "native") and not args.matches
+    if world == 1 and default_shape and not args.no_extra:
+        del q, r
+        torch.cuda.empty_cache()
+        extra["stages"] = stage_records(args, torch, dist, dev)
 
     if rank == 0:
         pairs_total = b * world * args.steps
