@@ -110,6 +110,14 @@ int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, 
                     int n_map, int spread, int side, int32_t *owner_ws, double *flow,
                     void *stream);
 
+/* The same splat on (H, W) maps, as the flow demo writes it at the render's own resolution
+ *   data_creator/render_wt_pt_proj/get_of.py:52-60 (flow = zeros((540,960,2)); the caller masks by
+ *   truth_1 & truth_2, get_of.py:48, and passes un-cropped render coordinates).
+ * flow (n_map, H, W, 2) f64.  owner_ws (n_map, H*W) int32 scratch is needed unless H == W <= 448. */
+int ispa_flow_splat_hw(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
+                       int n_map, int spread, int H, int W, int32_t *owner_ws, double *flow,
+                       void *stream);
+
 /* Body of make_disparity for a batch of renders of one model, fused
  *   data_creator/make_disparity_syn.py:44-68 (get_3d_to_2d + prune_pts at the render's pose and at
  *   the pose turned by (10,10), masking by the first pose's truth, flow splat).

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ispa_crop_remap": (_i, [_p, _i64, _i, _p, _i, _i, _p, _p]),
     "ispa_project_prune": (_i, [_p, _i64, _p, _i, _p, _i, _i, _i, _i, _i, _d, _i, _p, _i, _p, _p, _p, _p, _p]),
     "ispa_flow_splat": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p]),
+    "ispa_flow_splat_hw": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _p, _p]),
     "ispa_make_disparity": (_i, [_p, _i64, _p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _p, _p]),
     "ispa_make_disparity_workspace_bytes": (_sz, [_i64, _i]),
     "ispa_make_disparity_ws": (_i, [_p, _i64, _p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _p, _p, _sz, _p]),

@@ -77,7 +77,7 @@ __device__ __forceinline__ int window_owner4(const int *img, int pw, int ly, int
 
 __global__ __launch_bounds__(kThreads) void flow_owner_kernel(const double *__restrict__ uv1,
                                                               const uint8_t *__restrict__ truth, int64_t n,
-                                                              int spread, int side,
+                                                              int spread, int h, int w,
                                                               int32_t *__restrict__ owner) {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int m = blockIdx.y;
@@ -87,22 +87,22 @@ __global__ __launch_bounds__(kThreads) void flow_owner_kernel(const double *__re
     int u, v;
     if (!to_int(r[i], u) || !to_int(r[n + i], v)) return;
     int y0, y1, x0, x1;
-    py_slice(v, spread, side, y0, y1);
-    py_slice(u, spread, side, x0, x1);
-    int32_t *o = owner + (int64_t)m * side * side;
+    py_slice(v, spread, h, y0, y1);
+    py_slice(u, spread, w, x0, x1);
+    int32_t *o = owner + (int64_t)m * h * w;
     const int32_t tag = (int32_t)i + 1;
     for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) atomicMax(&o[y * side + x], tag);
+        for (int x = x0; x < x1; ++x) atomicMax(&o[(int64_t)y * w + x], tag);
 }
 
 __global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__restrict__ uv1,
                                                                 const double *__restrict__ uv2, int64_t n,
-                                                                int side, const int32_t *__restrict__ owner,
+                                                                int64_t npix, const int32_t *__restrict__ owner,
                                                                 double *__restrict__ flow) {
-    const int pix = blockIdx.x * kThreads + threadIdx.x;
+    const int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int m = blockIdx.y;
-    if (pix >= side * side) return;
-    const int32_t o = owner[(int64_t)m * side * side + pix];
+    if (pix >= npix) return;
+    const int32_t o = owner[(int64_t)m * npix + pix];
     double2 val = make_double2(0.0, 0.0);
     if (o > 0) {
         const double *a = uv1 + (int64_t)m * 3 * n;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void flow_resolve_kernel(const double *__
         val.x = b[i] - a[i];
         val.y = b[n + i] - a[n + i];
     }
-    reinterpret_cast<double2 *>(flow)[(int64_t)m * side * side + pix] = val;
+    reinterpret_cast<double2 *>(flow)[(int64_t)m * npix + pix] = val;
 }
 
 // Flow splat with the owner image of one horizontal band of one map in LDS: every block scans all
@@ -553,19 +553,25 @@ __global__ __launch_bounds__(kThreads) void zbuffer_visibility_kernel(const doub
 
 }  // namespace
 
-extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
-                               int n_map, int spread, int side, int32_t *owner_ws, double *flow,
-                               void *stream) {
+namespace {
+
+// rows x cols flow maps; square maps of up to 8 LDS bands take the banded kernel
+int flow_splat_impl(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n, int n_map, int spread,
+                    int rows, int cols, int32_t *owner_ws, double *flow, void *stream) {
     ISPA_REQUIRE(n >= 0 && n_map >= 0 && n < (1ll << 31) - 1, "bad point count");
-    ISPA_REQUIRE(side > 0 && side <= 16384 && spread >= 0 && spread <= 64, "bad side/spread");
+    ISPA_REQUIRE(rows > 0 && rows <= 16384 && cols > 0 && cols <= 16384 && spread >= 0 && spread <= 64,
+                 "bad map size / spread");
     if (n_map == 0) return ISPA_OK;
     // up to 8 LDS bands per map (side <= 448): each band block scans all points once, no scratch image;
-    // larger maps take one global atomic per covered pixel on the owner image instead of hundreds of scans
-    const bool banded = (int64_t)side * side <= 8ll * kBandPixels;
-    ISPA_REQUIRE(flow && (owner_ws || banded), "null pointer (maps of more than %d pixels need owner_ws)", 8 * kBandPixels);
+    // larger (and rectangular) maps take one global atomic per covered pixel on the owner image instead of
+    // hundreds of scans
+    const int side = rows;
+    const bool banded = rows == cols && (int64_t)side * side <= 8ll * kBandPixels;
+    ISPA_REQUIRE(flow && (owner_ws || banded),
+                 "null pointer (rectangular maps and maps of more than %d pixels need owner_ws)", 8 * kBandPixels);
     ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
     hipStream_t s = (hipStream_t)stream;
-    const size_t npix = (size_t)side * side;
+    const size_t npix = (size_t)rows * cols;
     if (banded) {
         // banded LDS path (owner_ws is not touched)
         ISPA_REQUIRE(n == 0 || (uv1 && uv2 && truth), "null pointer");
@@ -590,12 +596,26 @@ extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8
     if (n > 0) {
         ISPA_REQUIRE(uv1 && uv2 && truth, "null pointer");
         hipLaunchKernelGGL(flow_owner_kernel, dim3(ispa::blocks_for(n, kThreads), n_map), dim3(kThreads), 0, s,
-                           uv1, truth, n, spread, side, owner_ws);
+                           uv1, truth, n, spread, rows, cols, owner_ws);
         if (int rc = ispa::check_launch("flow_owner_kernel")) return rc;
     }
     hipLaunchKernelGGL(flow_resolve_kernel, dim3(ispa::blocks_for((int64_t)npix, kThreads), n_map),
-                       dim3(kThreads), 0, s, uv1, uv2, n, side, owner_ws, flow);
+                       dim3(kThreads), 0, s, uv1, uv2, n, (int64_t)npix, owner_ws, flow);
     return ispa::check_launch("flow_resolve_kernel");
+}
+
+}  // namespace
+
+extern "C" int ispa_flow_splat(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
+                               int n_map, int spread, int side, int32_t *owner_ws, double *flow,
+                               void *stream) {
+    return flow_splat_impl(uv1, uv2, truth, n, n_map, spread, side, side, owner_ws, flow, stream);
+}
+
+extern "C" int ispa_flow_splat_hw(const double *uv1, const double *uv2, const uint8_t *truth, int64_t n,
+                                  int n_map, int spread, int H, int W, int32_t *owner_ws, double *flow,
+                                  void *stream) {
+    return flow_splat_impl(uv1, uv2, truth, n, n_map, spread, H, W, owner_ws, flow, stream);
 }
 
 extern "C" int ispa_point_depth_splat(const double *pt_render, int64_t n, int H, int W, int radius,

@@ -2,7 +2,9 @@
 
 Drop-in for data_creator/make_disparity_syn.py: `make_disparity_maps` is the data-in /
 data-out core of the per-image body (lines 44-68), batched over images; `make_disparity`
-keeps the script's directory-walking entry point (lines 17-70).
+keeps the script's directory-walking entry point (lines 17-70).  `demo_flow` is the flow demo
+of data_creator/render_wt_pt_proj/get_of.py:38-62 (render resolution, no crop, both poses'
+truths).
 """
 import os
 
@@ -14,13 +16,16 @@ from . import _abi, _device as dv, io_utils, pt2render, run_proj
 FLOW_SIDE = 224          # make_disparity_syn.py:61
 SPREAD = 2               # make_disparity_syn.py:63
 POSE_STEP = (10.0, 10.0)  # make_disparity_syn.py:49-50
+DEMO_SIZE = (540, 960)   # get_of.py:54
+DEMO_STEP = (10.0, 0.0)  # get_of.py:43-44
 
 
 def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
     """make_disparity_syn.py:55-68 for already projected points.
 
     uv1, uv2 (n_map,3,N) or (3,N) crop coordinates at pose 1 / pose 2, truth (n_map,N) = truth_1.
-    Returns flow (n_map,side,side,2) float64 (or (side,side,2))."""
+    side: an int (square maps) or (H, W) as in get_of.py:54.
+    Returns flow (n_map,H,W,2) float64 (or (H,W,2))."""
     as_tensor = dv.is_tensor(uv1)
     a = dv.to_dev(uv1, torch.float64)
     b = dv.to_dev(uv2, torch.float64)
@@ -29,11 +34,12 @@ def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
     if single:
         a, b, t = a[None], b[None], t[None]
     n_map, _, n = a.shape
-    # maps of up to 8 x 25088 pixels (side <= 448) run the banded LDS kernel, which needs no owner image
-    owner = None if side * side <= 8 * 25088 else dv.empty((n_map, side * side), torch.int32)
-    flow = dv.empty((n_map, side, side, 2), torch.float64)
-    _abi.check(_abi.lib.ispa_flow_splat(dv.ptr(a), dv.ptr(b), dv.ptr(t), n, n_map, int(spread), int(side),
-                                        dv.ptr(owner), dv.ptr(flow), dv.stream_ptr()))
+    h, w = (int(side), int(side)) if np.isscalar(side) else (int(side[0]), int(side[1]))
+    # square maps of up to 8 x 25088 pixels (side <= 448) run the banded LDS kernel, which needs no owner image
+    owner = None if h == w and h * w <= 8 * 25088 else dv.empty((n_map, h * w), torch.int32)
+    flow = dv.empty((n_map, h, w, 2), torch.float64)
+    _abi.check(_abi.lib.ispa_flow_splat_hw(dv.ptr(a), dv.ptr(b), dv.ptr(t), n, n_map, int(spread), h, w,
+                                           dv.ptr(owner), dv.ptr(flow), dv.stream_ptr()))
     if single:
         flow = flow[0]
     return dv.back(flow, as_tensor)
@@ -84,6 +90,38 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
     truth1, uv1 = run_proj.project_prune(pts, cams1, shared, crops)
     _, uv2 = run_proj.project_prune(pts, cams2, shared, crops)
     flow = flow_splat(uv1, uv2, truth1)
+    return dv.back(flow, as_tensor)
+
+
+def demo_flow(key_3d, params, depth_maps, step=DEMO_STEP, spread=SPREAD):
+    """data_creator/render_wt_pt_proj/get_of.py:38-62 for a batch of views of ONE model: project at `params` and at
+    the pose turned by `step` (azimuth +10 in the script), prune both against the SAME depth image without a crop,
+    keep the points visible at both poses (line 48) and splat (uv2 - uv1) of the first pose's render coordinates
+    into a flow map of the depth image's size.
+
+    key_3d (N,3); params (n_map,4) or [azimuth, elevation, tilt, rho] (the script truncates them to integers,
+    line 29: pass them truncated to reproduce it); depth_maps (n_map,H,W) f32, or one (H,W) image shared by all
+    views.  Returns flow (n_map,H,W,2) float64 ((H,W,2) for a single params row), numpy unless key_3d is a
+    device tensor."""
+    as_tensor = dv.is_tensor(key_3d)
+    single = np.ndim(params) == 1
+    params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    more = params.copy()
+    more[:, 0] += step[0]
+    more[:, 1] += step[1]
+    cams1 = np.stack([run_proj.camera_from_params(p) for p in params])
+    cams2 = np.stack([run_proj.camera_from_params(p) for p in more])
+    pts = dv.to_dev(key_3d, torch.float64)
+    depth = dv.to_dev(depth_maps, torch.float32)
+    if depth.dim() == 3 and depth.shape[0] == 1:
+        depth = depth[0]
+    if depth.dim() == 3 and depth.shape[0] != params.shape[0]:
+        raise ValueError("need one depth map per view or a single shared one")
+    truth1, uv1 = run_proj.project_prune(pts, cams1, depth)
+    truth2, uv2 = run_proj.project_prune(pts, cams2, depth)
+    flow = flow_splat(uv1, uv2, truth1 & truth2, side=tuple(depth.shape[-2:]), spread=spread)
+    if single:
+        flow = flow[0]
     return dv.back(flow, as_tensor)
 
 

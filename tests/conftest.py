@@ -25,6 +25,21 @@ def golden_disparity():
 
 
 @pytest.fixture(scope="session")
+def golden_demo_flow():
+    return np.load(os.path.join(GOLDEN, "demo_flow.npz"))
+
+
+def dense_flow(z, tag):
+    """The (540, 960, 2) flow map of a demo_flow.npz case from its sparse storage, checked against its SHA-256."""
+    import hashlib
+    flow = np.zeros((540 * 960, 2))
+    flow[z[f"{tag}_flow_pixels"]] = z[f"{tag}_flow_values"]
+    flow = flow.reshape(540, 960, 2)
+    assert hashlib.sha256(flow.tobytes()).digest() == z[f"{tag}_flow_sha256"].tobytes()
+    return flow
+
+
+@pytest.fixture(scope="session")
 def golden_correlation():
     return np.load(os.path.join(GOLDEN, "correlation.npz"))
 

@@ -21,8 +21,8 @@ Read as data: data_creator/render_wt_pt_proj/z_map/temp0001.exr (the one depth r
 What cannot be imported here (cv2 / trimesh / OpenEXR / caffe missing) and is therefore
 re-typed below on top of the imported primitives, following the cited lines:
   run_proj.get_3d_to_2d / prune_pts (run_proj.py:24-46), make_disparity's body
-  (make_disparity_syn.py:44-68), io_utils.get_render_array / get_pt_depth_map
-  (io_utils.py:97-124).
+  (make_disparity_syn.py:44-68), the flow demo's body (render_wt_pt_proj/get_of.py:38-62),
+  io_utils.get_render_array / get_pt_depth_map (io_utils.py:97-124).
 """
 import hashlib
 import importlib.util
@@ -112,6 +112,27 @@ def ref_make_disparity_body(key_3d, params, depth_map, crop_params):    # make_d
         flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 0] = del_azi[:, i][0]
         flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 1] = del_azi[:, i][1]
     return flow, truth_1, truth_2
+
+
+def ref_get_of_body(key_3d, params, depth_map):                        # get_of.py:38-62
+    params = list(params)
+    key_2d_norm = ref_get_3d_to_2d(ref_a, key_3d, params)
+    truth_1, key_2d = ref_prune_pts(key_2d_norm, depth_map)
+    params[0] += 10
+    params[1] += 0
+    key_2d_more = ref_get_3d_to_2d(ref_a, key_3d, params)
+    truth_2, key_2d = ref_prune_pts(key_2d_more, depth_map)
+    truth = truth_1.astype('bool') & truth_2.astype('bool')
+    key_2d_more = np.copy(key_2d_more[:, truth])
+    key_2d_norm = np.copy(key_2d_norm[:, truth])
+    del_azi = key_2d_more - key_2d_norm
+    flow = np.zeros((540, 960, 2))
+    k = 2
+    for i in range(key_2d_norm.shape[1]):
+        pt = key_2d_norm[:, i][:2].astype(int)
+        flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 0] = del_azi[:, i][0]
+        flow[pt[1] - k:pt[1] + k, pt[0] - k:pt[0] + k, 1] = del_azi[:, i][1]
+    return flow, truth
 
 
 def ref_get_render_array(file_dict, model_pts, depth_map):              # io_utils.py:97-117
@@ -267,6 +288,40 @@ def gen_disparity():
     print("disparity.npz", len(out), "arrays")
 
 
+def gen_demo_flow():
+    """get_of.py's flow demo on (i) a cloud, (ii) jittered vertices of the shipped bed mesh against the depth
+    render the reference ships for that mesh (z_map/temp0001.exr: the script's own depth_file), (iii) a close-up
+    whose points reach the image border (empty Python slices at the top / left, cut ones at the bottom / right)."""
+    from pose_estimation_amd import exr
+    out = {}
+    verts = load_obj_vertices()
+    rs = np.random.RandomState(17)
+    cloud = rs.uniform(-0.35, 0.35, (5000, 3))
+    mesh_cloud = verts[rs.randint(0, len(verts), 6000)] + rs.normal(0, 0.002, (6000, 3))
+    shipped = exr.read_exr_channel(open(f"{REF}/data_creator/render_wt_pt_proj/z_map/temp0001.exr", "rb").read(), "R")
+    for tag, pts, params, depth in (("cloud", cloud, [30, 10, 0, 3], None),
+                                    ("mesh", mesh_cloud, [135, 20, -5, 2], None),
+                                    ("border", cloud, [300, 0, 0, 1], None),
+                                    ("shipped", mesh_cloud, [0, 0, 0, 2], shipped)):
+        if depth is None:
+            depth = surface_depth_map(ref_get_3d_to_2d(ref_a, pts, params))
+        flow, truth = ref_get_of_body(pts, params, depth)
+        nz = np.flatnonzero(flow.any(axis=2).ravel())
+        out[f"{tag}_pts"] = pts
+        out[f"{tag}_params"] = np.array(params, dtype=np.float64)
+        if tag != "shipped":                               # the shipped render is read from its crop fixture's source
+            out[f"{tag}_depth"] = depth
+        out[f"{tag}_truth"] = truth
+        out[f"{tag}_flow_pixels"] = nz.astype(np.int32)    # the map is mostly empty: stored sparse
+        out[f"{tag}_flow_values"] = flow.reshape(-1, 2)[nz]
+        out[f"{tag}_flow_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(flow).tobytes()).digest(),
+                                                  dtype=np.uint8)
+        print(tag, "kept", int(truth.sum()), "pixels", len(nz))
+    out["shipped_depth"] = shipped
+    np.savez_compressed(os.path.join(HERE, "demo_flow.npz"), **out)
+    print("demo_flow.npz", len(out), "arrays")
+
+
 def gen_correlation():
     import torch
     sys.path.insert(0, f"{REF}/classifier_code")
@@ -413,7 +468,9 @@ def gen_exr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables", "exr"]
+    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables", "exr", "demo_flow"]
+    if "demo_flow" in which:
+        gen_demo_flow()
     if "exr" in which:
         gen_exr()
     if "acmm" in which:

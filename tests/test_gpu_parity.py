@@ -355,6 +355,63 @@ def test_flow_splat_wild_coordinates(pea, spread, side):
     assert np.count_nonzero(want) > 0
 
 
+@pytest.mark.parametrize("spread,h,w", [(2, 540, 960), (2, 960, 540), (1, 7, 300), (3, 448, 447), (5, 33, 1200), (2, 1, 5)])
+def test_flow_splat_rectangular_maps(pea, spread, h, w):
+    """(H, W) maps as the flow demo writes them (get_of.py:54-60): rows wrap and clip against H, columns against W."""
+    rs = np.random.RandomState(7 * h + w + spread)
+    n = 5000
+    uv = np.stack([rs.randint(-2 * w - 9, 2 * w + 9, n), rs.randint(-2 * h - 9, 2 * h + 9, n),
+                   np.ones(n)]).astype(np.float64)
+    uv[:2, :600] = rs.randint(-2 * spread - 1, 2 * spread + 2, (2, 600))
+    uv[0, 600:1200] = w + rs.randint(-2 * spread - 1, 2 * spread + 2, 600)
+    uv[1, 600:1200] = h + rs.randint(-2 * spread - 1, 2 * spread + 2, 600)
+    uv[0, 1200:1800] = -w + rs.randint(-2 * spread - 1, 2 * spread + 2, 600)
+    uv[1, 1200:1800] = -h + rs.randint(-2 * spread - 1, 2 * spread + 2, 600)
+    uv[0, 1800:3200] = rs.randint(0, w, 1400)
+    uv[1, 1800:3200] = rs.randint(0, h, 1400)
+    uv[:2] += rs.uniform(0, 0.99, (2, n)) * np.sign(uv[:2])
+    uv2 = uv + rs.uniform(-9, 9, (3, n))
+    truth = rs.rand(n) > 0.2
+    got = pea.disparity.flow_splat(np.stack([uv, uv]), np.stack([uv2, uv2]), np.stack([truth, ~truth]), side=(h, w),
+                                   spread=spread)
+    assert got.shape == (2, h, w, 2)
+    for m, keep in enumerate((truth, ~truth)):
+        want = odisp.splat_flow_literal(uv[:, keep], (uv2 - uv)[:, keep], side=(h, w), k=spread)
+        assert np.array_equal(got[m], want)
+    assert np.count_nonzero(got) > 0
+
+
+@pytest.mark.parametrize("tag", ["cloud", "mesh", "border", "shipped"])
+def test_demo_flow_golden(pea, golden_demo_flow, tag):
+    """The flow demo (render_wt_pt_proj/get_of.py:38-62) against maps made by the imported reference primitives."""
+    from conftest import dense_flow
+    z = golden_demo_flow
+    want = dense_flow(z, tag)
+    got = pea.disparity.demo_flow(z[f"{tag}_pts"], z[f"{tag}_params"], z[f"{tag}_depth"])
+    assert got.shape == (540, 960, 2) and got.dtype == np.float64
+    assert np.array_equal(got, want)
+
+
+def test_demo_flow_batch_100k(pea):
+    rs = np.random.RandomState(3)
+    pts = rs.uniform(-0.4, 0.4, (100000, 3))
+    params = np.array([[30.0, 10.0, 0.0, 3.0], [250.0, 25.0, 5.0, 2.0]])
+    depths = []
+    for p in params:
+        d = ozb.zbuffer(og.get_3d_to_2d(pts, p), 540, 960, radius=2)[2]
+        d[~np.isfinite(d)] = 20.0
+        depths.append(d.astype(np.float32))
+    got = pea.disparity.demo_flow(pts, params, np.stack(depths))
+    for m in range(2):
+        want = odisp.demo_flow_core(pts, params[m].tolist(), depths[m])
+        assert np.array_equal(got[m], want) and np.count_nonzero(want) > 20000
+    shared = pea.disparity.demo_flow(pts, params, depths[0])
+    assert np.array_equal(shared[0], got[0])
+    assert np.array_equal(shared[1], odisp.demo_flow_core(pts, params[1].tolist(), depths[0]))
+    with pytest.raises(ValueError):
+        pea.disparity.demo_flow(pts, params, np.stack(depths + depths[:1]))
+
+
 def test_prune_pts_reads_the_exr_depth_render_itself(pea):
     """run_proj.prune_pts(pt_array, "<render>.png1.exr") as the reference calls it (run_proj.py:33-46,49-57):
     no .npy cache, no OpenEXR module; the depth image is the crop of the reference's own Blender render."""

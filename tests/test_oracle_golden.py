@@ -129,6 +129,19 @@ def test_splat_python_slice_semantics():
     assert g.py_slice_bounds(1, 2, 224) == (223, 223) and g.py_slice_bounds(-5, 2, 224) == (217, 221)
 
 
+@pytest.mark.parametrize("tag", ["cloud", "mesh", "border", "shipped"])
+def test_demo_flow(golden_demo_flow, tag):
+    """The flow demo (render_wt_pt_proj/get_of.py:38-62) re-typed on the imported reference primitives: 540 x 960
+    maps, no crop, points visible at both poses; 'shipped' runs against the depth render the reference ships."""
+    from conftest import dense_flow
+    z = golden_demo_flow
+    want = dense_flow(z, tag)
+    args = (z[f"{tag}_pts"], z[f"{tag}_params"].tolist(), z[f"{tag}_depth"])
+    assert np.array_equal(disparity.demo_flow_core(*args, literal=True), want)
+    assert np.array_equal(disparity.demo_flow_core(*args), want)
+    assert np.count_nonzero(want) > 1000
+
+
 @pytest.mark.parametrize("name", ANCHORS)
 def test_get_render_array_variant_b(golden_disparity, golden_geometry, name):
     z = golden_disparity
