@@ -29,6 +29,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef ISPA_TOP1_32X32
+#define ISPA_TOP1_32X32 0   // development switch: bfloat16 top-1 through the 32x32x16 kernel instead of the 16x16x32 one
+#endif
 #ifndef ISPA_ABLATE
 #define ISPA_ABLATE 0   // development switch for timing-only builds (results are wrong when non-zero):
 #endif                  // bf16 filter 1 = no top-list update, 2 = no chunk streaming; f32 filter 4, 5, 6 = both
@@ -1196,6 +1199,7 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
 #pragma unroll
                 for (int reg = ks * 16 / KS; reg < (ks + 1) * 16 / KS; ++reg) {
                     if (ISPA_ABLATE == 1) asm volatile("" ::"v"(prev[qi][reg]));
+                    else if constexpr (K == 1) best[qi].push4_step(reg & 3, prev[qi], reg & ~3, reg & ~3);
                     else best[qi].push(prev[qi][reg], reg);
                 }
             }
@@ -1326,24 +1330,34 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
     const unsigned lane_off[2] = {row_off + perm_seg(lane, 0) * 16, row_off + perm_seg(lane, 1) * 16};
     auto stage = [&](int64_t r0, int slot) {
-        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
+        // uniform: only a last chunk can be ragged.  Two code paths (the loads are volatile asm, so the
+        // compiler keeps the branch): the steady state pays no vector arithmetic for the ragged case
+        if (__builtin_expect(r0 + kBR <= rend, 1)) {
 #pragma unroll
-        for (int e = 0; e < kSeg; ++e) {
-            const int id = wq_u * kSeg + e;              // rows [8 id, 8 id + 8)
-            unsigned voff = lane_off[id & 1];
-            if (!full) {
-                const int64_t col = r0 + perm_seg(lane, id & 1) * 8;
-                voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+            for (int e = 0; e < kSeg; ++e) {
+                const int id = wq_u * kSeg + e;          // rows [8 id, 8 id + 8)
+                const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)r0) * 2u;
+                glds_b128(lane_off[id & 1], sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
             }
-            const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
-            glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
+        } else {
+#pragma unroll
+            for (int e = 0; e < kSeg; ++e) {
+                const int id = wq_u * kSeg + e;
+                const int64_t col = r0 + perm_seg(lane, id & 1) * 8;
+                const unsigned voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+                const uint64_t sbase = (uint64_t)rb + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
+            }
         }
     };
     float pre_nh = 0.f;
     bool pre_ok = false;
+    const int nh_lane = tid & (kBR - 1);
     auto fetch_nh = [&](int64_t r0) {
-        pre_ok = r0 + (tid & (kBR - 1)) < rend;
-        pre_nh = nhb[pre_ok ? r0 + (tid & (kBR - 1)) : 0];
+        // 32-bit lane arithmetic on a uniform base (rend - r0 fits an int: a split is at most nr < 2^27 long)
+        const int left = (int)(rend - r0);
+        pre_ok = nh_lane < left;
+        pre_nh = (nhb + r0)[pre_ok ? nh_lane : 0];
     };
     auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
     __syncthreads();
@@ -2711,7 +2725,7 @@ Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k)
     p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 256 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
     const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
-    p.t16 = p.bf16_mfma && k == 1;          // top-1: the 16x16x32 kernel
+    p.t16 = p.bf16_mfma && k == 1 && !ISPA_TOP1_32X32;          // top-1: the 16x16x32 kernel
     const int substreams =
         (p.t16 || p.split) ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
@@ -2956,7 +2970,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
                 case 7: rc = launch_t16<7>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
                 default: rc = launch_t16<8>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
             }
-        } else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        }
+#if ISPA_TOP1_32X32
+        else if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+#endif
+        else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
         if (rc) return rc;
     } else {
