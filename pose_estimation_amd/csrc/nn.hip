@@ -2812,7 +2812,11 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
 template <int KS32>
 int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                int64_t nr, const Plan &p, float *pval, int *pidx) {
+#ifdef ISPA_T16_ONE_BLOCK                           // development switch: one workgroup per CU (one wave per SIMD)
+    constexpr int lds_bytes = 100 * 1024;
+#else
     constexpr int lds_bytes = bf16_filter_lds_bytes<2 * KS32>();
+#endif
     static unsigned long long configured = 0;       // per instantiation, one bit per device
     if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32>), lds_bytes,
                                          &configured))
