@@ -1283,15 +1283,23 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kT16SubStreams = 4;    // partial result streams per (tile, split): lane >> 4
 
-template <int KS32>
-__global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t16_kernel(
+// NQ = 16-query tiles per wave.  NQ = 4 (what runs): 4 waves of 64 queries, two workgroups per CU up to 128
+// channels (two waves per SIMD, 192 registers each).  NQ = 2 (development switch ISPA_T16_NQ): 8 waves of 32
+// queries for the same 256-query block (C a multiple of 64, at most 128), 120 registers, four waves per SIMD.
+// Measured slower (1.88 against 1.77 ms per 512 pairs of 64x64x128): the loop is bound by instruction issue,
+// not by latency that more resident waves could hide, and a wave with half the query tiles reads the same
+// reference fragments and does the same bookkeeping for half the MFMAs.
+template <int KS32, int NQ>
+__global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf16_t16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
     int *__restrict__ part_idx) {
     constexpr int C = 32 * KS32;
     constexpr int KS = 2 * KS32;                        // 16-channel units, as in bf16_filter_lds_bytes
     constexpr int kRBuf = C * kRStride;
-    constexpr int kSeg = KS / 2;                        // LDS-direct instructions per wave per chunk
+    constexpr int kNT = 1024 / NQ;                      // threads
+    constexpr int kSeg = KS * NQ / 8;                   // LDS-direct instructions per wave per chunk
+    static_assert(NQ == 4 || (NQ == 2 && KS32 % 2 == 0), "8 waves share the chunk pieces evenly only if C % 64 == 0");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *rbuf = lds;
     float *nhbuf = reinterpret_cast<float *>(lds + 3 * kRBuf);
@@ -1315,8 +1323,8 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
 
     // ---- query tile -> LDS -> per-wave fragments in registers --------------------------------
 #pragma unroll
-    for (int e = 0; e < 2 * KS; ++e) {
-        const int seg = tid + kBThreads * e;
+    for (int e = 0; e < KS * NQ / 2; ++e) {
+        const int seg = tid + kNT * e;
         const int row = seg >> 5, col = (seg & 31) * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (q0 + col < nq) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)row * nq + q0 + col);
@@ -1361,12 +1369,12 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     };
     auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
     __syncthreads();
-    bf16x8 bq[4][KS32];
+    bf16x8 bq[NQ][KS32];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
+    for (int qt = 0; qt < NQ; ++qt)
 #pragma unroll
         for (int ks = 0; ks < KS32; ++ks)
-            bq[qt][ks] = tr_frag(lds + (ks * 32 + tr_row) * kQStride + (wq * 64 + qt * 16 + tr_col) * 2, kQStride);
+            bq[qt][ks] = tr_frag(lds + (ks * 32 + tr_row) * kQStride + (wq * 16 * NQ + qt * 16 + tr_col) * 2, kQStride);
     __syncthreads();
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
@@ -1378,9 +1386,9 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    TagTop1 best[4];
+    TagTop1 best[NQ];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) best[qt].init();
+    for (int qt = 0; qt < NQ; ++qt) best[qt].init();
 
     // fragment of reference tile `rt` (16 cells) of half-step `ri`, k-step `ks` of image `rimg`
     const int rd_perm = ((lane >> 3) & 1) | ((g & 1) << 1);   // (row bit 1) | (row bit 3) << 1 of this lane's rows
@@ -1394,11 +1402,11 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         return v;
     };
 
-    f32x4 acc_a[2][4], acc_b[2][4];
+    f32x4 acc_a[2][NQ], acc_b[2][NQ];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
+        for (int qt = 0; qt < NQ; ++qt) {
             acc_b[rt][qt] = f32x4{kNegInf, kNegInf, kNegInf, kNegInf};
             asm volatile("" : "+v"(acc_b[rt][qt]));     // opaque: keeps the loop from being peeled
         }
@@ -1409,11 +1417,11 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     // the best score is tracked once per chunk.  a[0..1] hold the two reference-tile fragments of
     // k-step 0 on entry and those of the next half-step on exit.
     auto half_step = [&](const char *rimg, int ri, const char *next_img, int next_ri, bf16x8 (&a)[2],
-                         const f32x4 (&init)[2], f32x4 (&now)[2][4], const f32x4 (&prev)[2][4], int prev_chunk,
+                         const f32x4 (&init)[2], f32x4 (&now)[2][NQ], const f32x4 (&prev)[2][NQ], int prev_chunk,
                          int prev_ri) {
         if (prev_ri == 0) {
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) best[qt].begin_half(prev_chunk);
+            for (int qt = 0; qt < NQ; ++qt) best[qt].begin_half(prev_chunk);
         }
 #pragma unroll
         for (int ks = 0; ks < KS32; ++ks) {
@@ -1430,17 +1438,17 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
+                for (int qt = 0; qt < NQ; ++qt) {
                     now[rt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt], bq[qt][ks],
                                                                           ks ? now[rt][qt] : init[rt], 0, 0, 0);
-                    // 32 scores per half-step spread over its 8 * KS32 MFMAs
+                    // 8 NQ scores per half-step spread over its 2 NQ * KS32 MFMAs
                     constexpr int per = 4 / KS32 > 0 ? 4 / KS32 : 1;
-                    const int m = (ks * 8 + rt * 4 + qt) * per;     // scores [m, m+per) of the previous half-step
+                    const int m = (ks * 2 * NQ + rt * NQ + qt) * per;     // scores [m, m+per) of the previous half-step
 #pragma unroll
                     for (int e = 0; e < per; ++e) {
                         const int sc = m + e;
-                        if (sc < 32) {
-                            const int prt = sc >> 4, pqt = (sc >> 2) & 3, reg = sc & 3;
+                        if (sc < 8 * NQ) {
+                            const int prt = sc / (4 * NQ), pqt = (sc >> 2) % NQ, reg = sc & 3;
                             if (ISPA_ABLATE == 1 || ISPA_ABLATE == 13 || ISPA_ABLATE == 123)
                                 asm volatile("" ::"v"(prev[prt][pqt][reg]));
                             else
@@ -1452,14 +1460,14 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
             a[0] = an[0];
             a[1] = an[1];
         }
-        if (KS32 == 3) {                                 // 24 MFMAs covered 24 scores: the rest here
+        if (KS32 == 3) {                                 // 24 MFMAs covered 24 scores: the rest here (NQ = 4)
 #pragma unroll
             for (int sc = 24; sc < 32; sc += 4)
                 best[(sc >> 2) & 3].push4(prev[sc >> 4][(sc >> 2) & 3], prev_ri * 8 + (sc >> 4) * 4);
         }
         if (prev_ri == 1) {
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) best[qt].end_half();
+            for (int qt = 0; qt < NQ; ++qt) best[qt].end_half();
         }
     };
 
@@ -1494,7 +1502,7 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {                                   // second half of the last chunk
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
+        for (int qt = 0; qt < NQ; ++qt) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) best[qt].push4(acc_b[rt][qt], 8 + rt * 4);
             best[qt].end_half();
@@ -1510,8 +1518,8 @@ __global__ __launch_bounds__(kBThreads, KS32 > 4 ? 1 : 2) void nn_filter_bf16_t1
         return (int)(rbeg + (int64_t)(code >> 4) * kBR + (tag >> 2) * 16 + 4 * g + (tag & 3));
     };
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-        store_partial<2>(best[qt], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 64 + qt * 16 + l15);
+    for (int qt = 0; qt < NQ; ++qt)
+        store_partial<2>(best[qt], to_ref, part_val, part_idx, b, nparts, part, nq, q0 + wq * 16 * NQ + qt * 16 + l15);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2809,19 +2817,20 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
     return ISPA_OK;
 }
 
+#ifndef ISPA_T16_NQ
+#define ISPA_T16_NQ 4        // development switch: 2 = the 8-wave form of the top-1 kernel for 64 / 128 channels
+#endif
 template <int KS32>
 int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
                int64_t nr, const Plan &p, float *pval, int *pidx) {
-#ifdef ISPA_T16_ONE_BLOCK                           // development switch: one workgroup per CU (one wave per SIMD)
-    constexpr int lds_bytes = 100 * 1024;
-#else
     constexpr int lds_bytes = bf16_filter_lds_bytes<2 * KS32>();
-#endif
+    // 4 waves of 64 queries; the 8-wave form (64 or 128 channels) is slower: 1.88 against 1.77 ms per 512 pairs
+    constexpr int NQ = (KS32 % 2 == 0 && KS32 <= 4) ? ISPA_T16_NQ : 4;
     static unsigned long long configured = 0;       // per instantiation, one bit per device
-    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32>), lds_bytes,
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_t16_kernel<KS32, NQ>), lds_bytes,
                                          &configured))
         return rc;
-    hipLaunchKernelGGL((nn_filter_bf16_t16_kernel<KS32>), grid, dim3(kBThreads), lds_bytes, s, q, r, rnh, nq, nr,
+    hipLaunchKernelGGL((nn_filter_bf16_t16_kernel<KS32, NQ>), grid, dim3(1024 / NQ), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
     return ISPA_OK;
 }
