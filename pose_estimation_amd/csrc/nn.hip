@@ -1027,7 +1027,6 @@ __device__ __forceinline__ int perm_seg(int lane, int par) {
 
 constexpr int kBQ = 256;             // queries per block
 constexpr int kBR = 64;              // references per chunk
-constexpr int kBThreads = 256;
 constexpr int kBSubStreams = 2;      // partial result streams per (tile, split): the two lane halves
 constexpr int kRStride = 128;        // bytes per LDS row of 64 bf16 reference cells (swizzled, not padded)
 constexpr int kQStride = 512 + 64;   // bytes per LDS row of 256 bf16 query cells
