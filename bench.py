@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--sorted", "--morton", dest="morton", action="store_true",
                     help="geometry workloads: put the model points in space-filling-curve order first "
                          "(run_proj.spatial_order, once per model), so that neighbouring lanes hit neighbouring pixels")
+    ap.add_argument("--as-generated", action="store_true",
+                    help="disparity: process the points in the order they were generated in (ispa_make_disparity_ws) "
+                         "instead of along a space-filling curve with the generated order as ranks "
+                         "(ispa_make_disparity_ordered; same maps)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' with ranks sharing one GPU rehearses the multi-rank "
                          "code path on a single-GPU box (not a measurement)")
@@ -193,6 +197,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
     import pose_estimation_amd as pea
     from pose_estimation_amd import _abi, _device as dv, sharding
     n = args.points
+    point_order_note = None
     rs = np.random.RandomState(100 + rank)
     pts_np = synthetic_model(args.model, n, 100 + rank)
     if args.workload == "zbuffer" and not args.unfused:
@@ -331,18 +336,30 @@ def run_geometry(args, torch, dist, world, rank, dev):
         else:
             need = _abi.lib.ispa_make_disparity_workspace_bytes(n, M)
             dws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+            # the model's points along a Hilbert curve (once per model, outside the timed region), ranks = the order
+            # they were generated in: the flow maps are those of the generated order, bit for bit
+            ordered = not (args.one_launch or args.morton or args.as_generated)
+            po = pea.disparity.PointOrder(pts_np) if ordered else None
 
             def step():
                 if args.one_launch:
                     _abi.check(_abi.lib.ispa_make_disparity(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
                                                             depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
                                                             crops.data_ptr(), 1, 2, flow.data_ptr(), st()))
+                elif po is not None:
+                    _abi.check(_abi.lib.ispa_make_disparity_ordered(
+                        po.points.data_ptr(), po.rank.data_ptr(), po.inverse.data_ptr(), n, cams1.data_ptr(),
+                        cams2.data_ptr(), M, depth.data_ptr(), 1, 540, 960, 540, 950, 0.15, crops.data_ptr(), 1, 2,
+                        flow.data_ptr(), dws.data_ptr(), need, st()))
                 else:
                     _abi.check(_abi.lib.ispa_make_disparity_ws(pts.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(), M,
                                                                depth.data_ptr(), 1, 540, 960, 540, 950, 0.15,
                                                                crops.data_ptr(), 1, 2, flow.data_ptr(),
                                                                dws.data_ptr(), need, st()))
             units, unit_name, recs = M, "maps/s", 1
+            if po is not None:
+                point_order_note = ("processed along a hilbert curve (disparity.PointOrder), ranked as generated: the "
+                                    "maps of the generated order")
             # fused: points read once per map, one depth gather per point, the flow map written
             alg_bytes = [(24.0 * n + 4.0 * n + 802816.0) * M]
             names = ["make_disparity" if args.one_launch else "make_disparity_ws"]
@@ -389,7 +406,8 @@ def run_geometry(args, torch, dist, world, rank, dev):
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "f32" if args.workload == "corr" else "f64", "data": "synthetic",
         "config": {"workload": workload, "points": n, "model": MODEL_NAMES[args.model],
-                   "point_order": "hilbert curve (run_proj.spatial_order)" if args.morton else "as generated"},
+                   "point_order": point_order_note or ("hilbert curve (run_proj.spatial_order)" if args.morton
+                                                       else "as generated")},
         "roofline": dict(roof, traffic=traffic, traffic_source=traffic_src, kernel=names[dom],
                          kernel_ms=round(per[dom], 4), work_per_launch=alg_bytes[dom],
                          all_kernels_ms={f"{i}:{names[i]}": round(per[i], 4) for i in range(recs)}),
@@ -409,6 +427,7 @@ def stage_records(args, torch, dist, dev):
         a = copy.copy(args)
         a.workload, a.steps, a.warmup, a.no_cpu_baseline = wl, 5, 2, True
         a.poses, a.maps, a.points, a.model, a.unfused, a.one_launch, a.morton = 3600, 256, 100000, "chair", False, False, False
+        a.as_generated = False
         rec = run_geometry(a, torch, dist, 1, 0, dev)
         roof = rec["roofline"]
         out[wl] = {"value": rec["value"], "unit": rec["unit"], "steps": a.steps, "ms_per_step": rec["ms_per_step"],

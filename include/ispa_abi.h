@@ -139,6 +139,20 @@ int ispa_make_disparity_ws(const double *pts, int64_t n, const double *cams1, co
                            int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
                            double *flow, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same body for points given in a processing order of the caller's choice.  make_disparity's result depends on
+ * the order of the points (the last point written wins a pixel, make_disparity_syn.py:65-68); this entry point
+ * separates the order the points are PROCESSED in from the order that decides who wins: pts (n,3) is the model in
+ * processing order (e.g. along a space-filling curve, so that neighbouring lanes gather neighbouring depth texels),
+ * rank (n) int32 gives each of them its index in the reference's order, inverse (n) int32 is the inverse
+ * permutation (inverse[rank[i]] = i).  Same flow maps, bit for bit, as ispa_make_disparity_ws on the points in the
+ * reference's order.  rank = inverse = NULL: array order, i.e. ispa_make_disparity_ws.  A rank outside [0, n) drops
+ * its point; nothing outside the arrays is read. */
+int ispa_make_disparity_ordered(const double *pts, const int32_t *rank, const int32_t *inverse, int64_t n,
+                                const double *cams1, const double *cams2, int n_map, const float *depth,
+                                int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+                                const int32_t *crop, int crop_per_map, int spread, double *flow,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* get_pt_depth_map(render_array, size, radius)
  *   classifier_code/train_test_scripts/utils/io_utils.py:119-124: z splat, last writer wins.
  * owner_ws (H*W) int32 scratch; depth_out (H,W) f64. */

@@ -43,6 +43,8 @@ SIGNATURES = {
     "ispa_make_disparity": (_i, [_p, _i64, _p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _p, _p]),
     "ispa_make_disparity_workspace_bytes": (_sz, [_i64, _i]),
     "ispa_make_disparity_ws": (_i, [_p, _i64, _p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _p, _p, _sz, _p]),
+    "ispa_make_disparity_ordered": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p, _i, _i, _i, _i, _i, _d, _p, _i, _i, _p, _p, _sz,
+                                         _p]),
     "ispa_point_depth_splat": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p]),
     "ispa_zbuffer": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "ispa_zbuffer_visibility": (_i, [_p, _i64, _i, _p, _i, _i, _d, _p, _p]),

@@ -385,11 +385,15 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
     }
 }
 
-template <bool DILATE>
+// ORDERED: the points arrive in a processing order of the caller's choice (e.g. along a space-filling curve, so
+// that the points kernel's depth gathers coalesce) and rank[i] is point i's index in the reference's order: the
+// kept point with the highest RANK wins a pixel, and inverse[rank] finds it again for the flow value.  Ranks
+// outside [0, n) drop their point and a bad inverse entry leaves the pixel empty: no read outside the arrays.
+template <bool DILATE, bool ORDERED>
 __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
     const int32_t *__restrict__ rec, const int32_t *__restrict__ crop, int crop_per_map, int spread, int band_rows,
-    double *__restrict__ flow) {
+    double *__restrict__ flow, const int32_t *__restrict__ rank, const int32_t *__restrict__ inverse) {
     using namespace ispa_geom;
     extern __shared__ int owner[];
     constexpr int side = (int)kCropSide;
@@ -404,18 +408,20 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     const int32_t *rm = rec + (int64_t)m * n;
     constexpr int kBatch = 8;
     for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
-        int r[kBatch];
+        int r[kBatch], rk[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
             r[e] = rm[i < n ? i : 0];
+            rk[e] = ORDERED ? rank[i < n ? i : 0] : (int)i;
         }
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
             if (i >= n || r[e] < 0) continue;
+            if (ORDERED && (unsigned)rk[e] >= (unsigned)n) continue;
             const int iu = r[e] & 0xffff, iv = r[e] >> 16;
-            const int tag = (int)i + 1;
+            const int tag = rk[e] + 1;
             if (DILATE) {
                 // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
                 // below the spread and anchored at c - spread otherwise
@@ -446,8 +452,12 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
         const int o = DILATE ? (w == 4 ? window_owner4(owner, pw, p / side, p % side) : window_owner(owner, pw, p / side, p % side, w))
                              : owner[p];
         double2 val = make_double2(0.0, 0.0);
-        if (o > 0) {
-            const int64_t i = o - 1;
+        int64_t i = o - 1;
+        if (ORDERED && o > 0) {
+            i = inverse[o - 1];
+            if (i < 0 || i >= n) i = -1;
+        }
+        if (i >= 0) {
             const double x = pts[3 * i], y = pts[3 * i + 1], zz = pts[3 * i + 2];
             double u1, v1, u2, v2, z;
             project_point(P1, x, y, zz, u1, v1, z);
@@ -690,7 +700,8 @@ extern "C" int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n
 namespace {
 int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
                         const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
-                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream);
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream,
+                        const int32_t *rank = nullptr, const int32_t *inverse = nullptr);
 }
 
 extern "C" size_t ispa_make_disparity_workspace_bytes(int64_t n, int n_map) {
@@ -711,6 +722,21 @@ extern "C" int ispa_make_disparity_ws(const double *pts, int64_t n, const double
                                crop_per_map, spread, flow, (int32_t *)workspace, stream);
 }
 
+extern "C" int ispa_make_disparity_ordered(const double *pts, const int32_t *rank, const int32_t *inverse, int64_t n,
+                                           const double *cams1, const double *cams2, int n_map, const float *depth,
+                                           int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+                                           const int32_t *crop, int crop_per_map, int spread, double *flow,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    ISPA_REQUIRE(n >= 0 && n_map >= 0, "negative size");
+    ISPA_REQUIRE((rank != nullptr) == (inverse != nullptr), "rank and inverse come together (both NULL = array order)");
+    if (workspace_bytes < ispa_make_disparity_workspace_bytes(n, n_map))
+        return ispa::fail(ISPA_EWORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes,
+                          ispa_make_disparity_workspace_bytes(n, n_map));
+    ISPA_REQUIRE(workspace != nullptr || n == 0 || n_map == 0, "null workspace");
+    return make_disparity_impl(pts, n, cams1, cams2, n_map, depth, depth_per_map, H, W, ylim, xlim, relax, crop,
+                               crop_per_map, spread, flow, (int32_t *)workspace, stream, rank, inverse);
+}
+
 extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const double *cams2,
                                    int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,
                                    int xlim, double relax, const int32_t *crop, int crop_per_map, int spread,
@@ -722,7 +748,8 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
 namespace {
 int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
                         const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
-                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream) {
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream,
+                        const int32_t *rank, const int32_t *inverse) {
     ISPA_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && n_map >= 0, "bad point count");
     ISPA_REQUIRE(spread >= 0 && spread <= 64, "bad spread");
     if (n_map == 0) return ISPA_OK;
@@ -744,10 +771,14 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
         return rc;
     if (rec && n > 0) {
         // with a workspace: the per-point part once per (map, point), then the band blocks on its records
-        static unsigned long long configured_b[2] = {0, 0};
-        if (int rc = ispa::allow_dynamic_lds(dilate ? reinterpret_cast<const void *>(&disparity_bands_kernel<true>)
-                                                    : reinterpret_cast<const void *>(&disparity_bands_kernel<false>),
-                                             kMaxBandLds, &configured_b[dilate]))
+        static unsigned long long configured_b[4] = {0, 0, 0, 0};
+        const bool ordered = rank != nullptr;
+        void (*bands)(const double *, int64_t, const double *, const double *, const int32_t *, const int32_t *, int,
+                      int, int, double *, const int32_t *, const int32_t *) =
+            ordered ? (dilate ? disparity_bands_kernel<true, true> : disparity_bands_kernel<false, true>)
+                    : (dilate ? disparity_bands_kernel<true, false> : disparity_bands_kernel<false, false>);
+        if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(bands), kMaxBandLds,
+                                             &configured_b[2 * ordered + dilate]))
             return rc;
         const ispa::TimingSlot timed = ispa::timing_begin(s);
         const int nbx = (int)ispa::blocks_for(n, 256 * kPointsPerThread);
@@ -755,9 +786,8 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
         ISPA_REQUIRE(nblocks < (1ll << 31), "too many points x maps for one launch");
         hipLaunchKernelGGL(disparity_points_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, pts, n, cams1, depth,
                            depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, n_map, nbx, rec);
-        hipLaunchKernelGGL(dilate ? disparity_bands_kernel<true> : disparity_bands_kernel<false>, dim3(nbands, n_map),
-                           dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, rec, crop, crop_per_map, spread,
-                           band_rows, flow);
+        hipLaunchKernelGGL(bands, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, rec, crop,
+                           crop_per_map, spread, band_rows, flow, rank, inverse);
         ispa::timing_end(timed, s);
         return ispa::check_launch("disparity_bands_kernel");
     }

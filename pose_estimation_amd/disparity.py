@@ -45,7 +45,30 @@ def flow_splat(uv1, uv2, truth, side=FLOW_SIDE, spread=SPREAD):
     return dv.back(flow, as_tensor)
 
 
-def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
+class PointOrder:
+    """A model's points in a processing order of its own (by default along a Hilbert curve, run_proj.spatial_order),
+    with what the kernels need to keep the reference's order as the one that decides which point wins a pixel:
+    `points` (N,3) device tensor in processing order, `rank` (N) int32 = each point's index in the original array,
+    `inverse` (N) int32 = where each original point went.  Build it once per model and pass it to
+    make_disparity_maps(point_order=...): same flow maps bit for bit, neighbouring lanes gather neighbouring depth
+    texels."""
+
+    def __init__(self, key_3d, perm=None):
+        pts = key_3d.detach().cpu().numpy() if dv.is_tensor(key_3d) else np.asarray(key_3d, dtype=np.float64)
+        if perm is None:
+            perm = run_proj.spatial_order(pts)
+        perm = np.asarray(perm, dtype=np.int64)
+        if perm.shape != (pts.shape[0],) or not np.array_equal(np.sort(perm), np.arange(pts.shape[0])):
+            raise ValueError("perm must be a permutation of the model's point indices")
+        inverse = np.empty_like(perm)
+        inverse[perm] = np.arange(perm.shape[0])
+        self.n = int(pts.shape[0])
+        self.points = dv.to_dev(np.ascontiguousarray(pts[perm]), torch.float64)
+        self.rank = dv.to_dev(perm.astype(np.int32), torch.int32)
+        self.inverse = dv.to_dev(inverse.astype(np.int32), torch.int32)
+
+
+def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, point_order=None):
     """Body of make_disparity for a batch of renders of ONE model.
 
     key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
@@ -54,8 +77,12 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
     fused=True runs the whole body in two launches without materialising projected coordinates
     (ispa_make_disparity_ws; ispa_make_disparity is the one-launch form for callers without a workspace); fused=False goes through
     project_prune twice and flow_splat, materialising the projected coordinates like the reference.
+    point_order: a PointOrder of key_3d (fused path only): the points are processed in its order, the results
+    are those of the given order.
     Returns flow (n_map,224,224,2) float64, numpy unless key_3d is a device tensor."""
     as_tensor = dv.is_tensor(key_3d)
+    if point_order is not None and (not fused or point_order.n != len(key_3d)):
+        raise ValueError("point_order goes with the fused path and must describe key_3d")
     params = np.atleast_2d(np.asarray(params, dtype=np.float64))
     n_map = params.shape[0]
     cams1 = np.stack([run_proj.camera_from_params(p) for p in params])
@@ -79,8 +106,10 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True):
         # one word of workspace per (render, point): the per-point work then runs once, not once per band
         need = _abi.lib.ispa_make_disparity_workspace_bytes(pts.shape[0], n_map)
         ws = dv.empty((max(need, 4),), torch.uint8)
-        _abi.check(_abi.lib.ispa_make_disparity_ws(
-            dv.ptr(pts), pts.shape[0], dv.ptr(c1), dv.ptr(c2), n_map, dv.ptr(depth), 1 if depth.shape[0] > 1 else 0,
+        po = point_order
+        _abi.check(_abi.lib.ispa_make_disparity_ordered(
+            dv.ptr(po.points if po else pts), dv.ptr(po.rank) if po else None, dv.ptr(po.inverse) if po else None,
+            pts.shape[0], dv.ptr(c1), dv.ptr(c2), n_map, dv.ptr(depth), 1 if depth.shape[0] > 1 else 0,
             h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, SPREAD,
             dv.ptr(flow), dv.ptr(ws), need, dv.stream_ptr()))
         return dv.back(flow, as_tensor)
@@ -132,6 +161,7 @@ def make_disparity(class_name, key_3d, image_dir, depth_dir, save_dir, template_
     del class_name
     os.makedirs(save_dir, exist_ok=True)
     images = sorted(x for x in os.listdir(image_dir) if template_model in x)
+    order = PointOrder(key_3d)                       # once per model; every batch of renders re-uses it
     for start in range(0, len(images), batch):
         chunk = images[start:start + batch]
         dicts = [io_utils.get_params_from_syn_file(x) for x in chunk]
@@ -139,7 +169,7 @@ def make_disparity(class_name, key_3d, image_dir, depth_dir, save_dir, template_
         crops = [d["crop_params"] for d in dicts]
         depth = np.stack([run_proj.get_depthmap_from_exr(os.path.join(depth_dir, io_utils.img_to_depth_file(x)))
                           for x in chunk])
-        flows = make_disparity_maps(key_3d, params, depth, crops)
+        flows = make_disparity_maps(key_3d, params, depth, crops, point_order=order)
         for name, flow in zip(chunk, flows):
             np.save(os.path.join(save_dir, name.split(".")[0]), flow)
     return len(images)

@@ -230,6 +230,69 @@ def test_make_disparity_batch_100k(pea):
     assert np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("tag", ["cloud", "mesh", "edge"])
+def test_make_disparity_processing_order_keeps_the_reference_order(pea, golden_disparity, tag):
+    """Points processed along a space-filling curve (or in any other order), ranks = the reference's order: the
+    flow maps are those of the reference's order, bit for bit."""
+    z = golden_disparity
+    pts = z[f"{tag}_pts"]
+    args = (z[f"{tag}_params"], z[f"{tag}_depth"], z[f"{tag}_crop"])
+    for perm in (None, np.random.RandomState(5).permutation(len(pts)), np.arange(len(pts))[::-1]):
+        order = pea.disparity.PointOrder(pts, perm)
+        flow = pea.disparity.make_disparity_maps(pts, *args, point_order=order)
+        assert np.array_equal(flow[0], z[f"{tag}_flow"])
+    with pytest.raises(ValueError):
+        pea.disparity.PointOrder(pts, np.zeros(len(pts), dtype=np.int64))
+    with pytest.raises(ValueError):
+        pea.disparity.make_disparity_maps(pts[:-1], *args, point_order=order)
+
+
+def test_make_disparity_ordered_100k_and_bad_ranks(pea):
+    import torch
+    from pose_estimation_amd import _abi, _device as dv
+    rs = np.random.RandomState(0)
+    pts = rs.uniform(-0.4, 0.4, (100000, 3))
+    params = np.array([[30.0, 10.0, 0.0, 3.0], [250.0, 25.0, 5.0, 2.6], [100.0, 0.0, -5.0, 2.2]])
+    depths, crops = [], []
+    for p in params:
+        r = og.get_3d_to_2d(pts, p)
+        d = ozb.zbuffer(r, 540, 960, radius=2)[2]
+        d[~np.isfinite(d)] = 20.0
+        depths.append(d.astype(np.float32))
+        t = og.depth_visibility_array_a(r, depths[-1])[0]
+        crops.append([int(r[1, t].min()) - 3, int(r[1, t].max()) + 3, int(r[0, t].min()) - 3, int(r[0, t].max()) + 3])
+    want = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
+    order = pea.disparity.PointOrder(pts)
+    got = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops), point_order=order)
+    assert np.array_equal(got, want) and np.count_nonzero(want) > 60000
+    # through the C ABI with ranks outside [0, n) and inverse entries outside it: points dropped, pixels left
+    # empty, nothing faults
+    n = len(pts)
+    bad_rank = order.rank.clone()
+    bad_rank[::7] = n + 5
+    bad_rank[3::7] = -2
+    bad_inv = order.inverse.clone()
+    bad_inv[::5] = n
+    cams1 = dv.to_dev(np.stack([pea.run_proj.camera_from_params(p) for p in params]), torch.float64)
+    more = params.copy()
+    more[:, :2] += 10
+    cams2 = dv.to_dev(np.stack([pea.run_proj.camera_from_params(p) for p in more]), torch.float64)
+    depth_t = dv.to_dev(np.stack(depths), torch.float32)
+    crop_t = dv.to_dev(np.array(crops), torch.int32)
+    flow = dv.empty((3, 224, 224, 2), torch.float64)
+    need = _abi.lib.ispa_make_disparity_workspace_bytes(n, 3)
+    ws = dv.empty((need,), torch.uint8)
+    _abi.check(_abi.lib.ispa_make_disparity_ordered(
+        dv.ptr(order.points), dv.ptr(bad_rank), dv.ptr(bad_inv), n, dv.ptr(cams1), dv.ptr(cams2), 3, dv.ptr(depth_t), 1,
+        540, 960, 540, 950, 0.15, dv.ptr(crop_t), 1, 2, dv.ptr(flow), dv.ptr(ws), need, dv.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.isfinite(flow.cpu().numpy()).all()
+    rc = _abi.lib.ispa_make_disparity_ordered(
+        dv.ptr(order.points), dv.ptr(bad_rank), None, n, dv.ptr(cams1), dv.ptr(cams2), 3, dv.ptr(depth_t), 1,
+        540, 960, 540, 950, 0.15, dv.ptr(crop_t), 1, 2, dv.ptr(flow), dv.ptr(ws), need, dv.stream_ptr())
+    assert rc == -1
+
+
 def test_script_entry_points_on_a_data_tree(pea, tmp_path, golden_geometry):
     """make_disparity / make_dense_keypoints over a directory laid out like the reference's ../data."""
     gv = pea.global_variables
