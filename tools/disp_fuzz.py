@@ -53,6 +53,11 @@ def main():
         got = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops))
         unfused = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops), fused=False)
         ok = np.array_equal(got, unfused)
+        # the same maps with the points processed in another order (curve order, or a random one), ranked as given
+        perm = None if rs.rand() < 0.5 else rs.permutation(len(pts))
+        ordered = pea.disparity.make_disparity_maps(pts, params, np.stack(depths), np.array(crops),
+                                                    point_order=pea.disparity.PointOrder(pts, perm))
+        ok = ok and np.array_equal(got, ordered)
         for k in range(m):
             want = odisp.make_disparity_core(pts, params[k].tolist(), depths[k], crops[k])
             ok = ok and np.array_equal(got[k], want)
