@@ -1017,6 +1017,24 @@ __device__ __forceinline__ void glds_b128(unsigned voff, uint64_t sbase, unsigne
         : "v"(voff), "s"(lds_dst), "s"(sbase)
         : "memory");
 }
+// The same instruction for a loop that issues many of them: the LDS destination is `lds_base + IMM`, added
+// straight into m0 (one scalar instruction), and m0 is NOT restored.  Nothing else in these kernels uses m0
+// (gfx9 LDS instructions do not read it), so the save / restore pair of glds_b128 is two scalar issue slots
+// per load for nothing; the callers keep `sbase` and `lds_base` in scalar registers themselves.
+template <int IMM>
+__device__ __forceinline__ void glds_b128_lean(unsigned voff, uint64_t sbase, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM)
+                 : "memory");
+}
+template <int E, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (E < N) {
+        f(std::integral_constant<int, E>{});
+        static_for<E + 1, N>(f);
+    }
+}
 // 16-byte segment (of the 8 in a 64-reference chunk row) that lane `lane` fetches when the 32-byte
 // slots of a row are permuted by (row bit 1) | (row bit 3) << 1; row bit 3 is the parity `par` of the
 // instruction index
@@ -1340,12 +1358,20 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         // uniform: only a last chunk can be ragged.  Two code paths (the loads are volatile asm, so the
         // compiler keeps the branch): the steady state pays no vector arithmetic for the ragged case
         if (__builtin_expect(r0 + kBR <= rend, 1)) {
-#pragma unroll
-            for (int e = 0; e < kSeg; ++e) {
+            // the chunk's column offset goes into the lane offsets (two vector adds per chunk), so that the
+            // scalar bases of the kSeg pieces are loop invariants; m0 = slot base + piece offset
+            const unsigned col2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)r0 * 2u));   // < 2^28
+            const unsigned v0 = lane_off[0] + col2, v1 = lane_off[1] + col2;
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * kRBuf + wq_u * kSeg * 1024));
+            static_for<0, kSeg>([&](auto ic) {
+                constexpr int e = decltype(ic)::value;
                 const int id = wq_u * kSeg + e;          // rows [8 id, 8 id + 8)
-                const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)r0) * 2u;
-                glds_b128(lane_off[id & 1], sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
-            }
+                uint64_t sbase = (uint64_t)rb + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sbase >> 32));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sbase);
+                sbase = ((uint64_t)hi << 32) | lo;
+                glds_b128_lean<e * 1024>((id & 1) ? v1 : v0, sbase, sb);
+            });
         } else {
 #pragma unroll
             for (int e = 0; e < kSeg; ++e) {
