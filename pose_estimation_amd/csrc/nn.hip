@@ -1404,9 +1404,9 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
         stage(clamp_chunk(1), 1);
-        fetch_nh(clamp_chunk(0));
-        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
-        fetch_nh(clamp_chunk(1));
+        if (wq_u == 0) fetch_nh(clamp_chunk(0));       // one wave stages the norm entries
+        if (wq_u == 0) nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        if (wq_u == 0) fetch_nh(clamp_chunk(1));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1513,11 +1513,11 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         const f32x4 init_b[2] = {load_init(nhbuf + slot * kBR, 1, 0), load_init(nhbuf + slot * kBR, 1, 1)};
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 0, rimg, 1, a, init_a, acc_a, acc_b, chunk - 1, 1);
-        nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
+        if (wq_u == 0) nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ISPA_ABLATE != 2 && ISPA_ABLATE != 123) stage(clamp_chunk(chunk + 2), after_slot);
-        fetch_nh(clamp_chunk(chunk + 2));
+        if (wq_u == 0) fetch_nh(clamp_chunk(chunk + 2));
         init_a[0] = load_init(nhbuf + next_slot * kBR, 0, 0);
         init_a[1] = load_init(nhbuf + next_slot * kBR, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
