@@ -164,6 +164,22 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         return None, None
 
 
+def profiled_mfma_util(workload_key, kernel_prefix, is_default_shape):
+    """Matrix-pipe utilisation of the filter kernel (SQ_VALU_MFMA_BUSY_CYCLES over the kernel's cycles on all 1024
+    SIMDs) from the newest committed rocprofv3 SQ pass of this same bench command, and the file it comes from: a
+    constant of that profile, not a measurement of this run."""
+    if not is_default_shape:
+        return None, None
+    try:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma_util.json")))[-1]
+        table = json.load(open(newest))[workload_key]
+        hits = [v["mfma_util"] for k, v in table.items() if k.startswith(kernel_prefix)]
+        return (hits[0], os.path.relpath(newest, ROOT)) if len(hits) == 1 else (None, None)
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None
+
+
 def measured_stream_rates(torch, dev, nbytes=1 << 31, reps=10):
     """(fill GB/s, copy GB/s counting read + write) of torch's own fill_ / copy_ on a 2 GiB buffer."""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -654,6 +670,9 @@ def main():
             "nn___dtype_" + args.dtype + ("___filter_split" if filt == "split" else ""),
             "nn_filter_split_kernel" if filt == "split" else "nn_filter_%s_kernel" % args.dtype,
             (b, g, c, args.k) == (512, 64, 128, 1) and not args.matches)
+        util, util_src = profiled_mfma_util(
+            "nn___dtype_" + args.dtype + ("___filter_split" if filt == "split" else ""), "nn_filter",
+            (b, g, c, args.k) == (512, 64, 128, 1) and not args.matches)
         out = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
             "value": round(pairs_total / elapsed, 2),
@@ -677,7 +696,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "nn_filter", "kernel_ms": round(filt_ms, 4),
-                         "flop_per_launch": flop_per_pair * b},
+                         "flop_per_launch": flop_per_pair * b,
+                         "mfma_util_profiled": util, "mfma_util_source": util_src},
         }
         if extra:
             out["extra"] = extra

@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
     auto stage = [&](int64_t r0, int slot) {
         // uniform: only a last chunk can be ragged.  Two code paths (the loads are volatile asm, so the
         // compiler keeps the branch): the steady state pays no vector arithmetic for the ragged case
-        if (__builtin_expect(r0 + kBR <= rend, 1)) {
+        if (__builtin_expect((int)(rend - r0) >= kBR, 1)) {      // 32-bit scalar compare (a split is < 2^27 long)
             // the chunk's column offset goes into the lane offsets (two vector adds per chunk), so that the
             // scalar bases of the kSeg pieces are loop invariants; m0 = slot base + piece offset
             const unsigned col2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)r0 * 2u));   // < 2^28
@@ -1504,10 +1504,12 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         init_a[0] = load_init(nhbuf, 0, 0);
         init_a[1] = load_init(nhbuf, 0, 1);
     }
-    int slot = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int next_slot = slot == 2 ? 0 : slot + 1;
-        const int after_slot = next_slot == 2 ? 0 : next_slot + 1;
+    // One chunk, in ring slot `slot` (a compile-time constant: the loop below is unrolled over the three slots,
+    // so every LDS address of the body is a loop-invariant lane register plus an immediate offset, and the
+    // staging's m0 values are constants - no per-chunk address arithmetic).
+    auto chunk_body = [&](int chunk, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        constexpr int next_slot = (slot + 1) % 3, after_slot = (slot + 2) % 3;
         const char *rimg = rbuf + slot * kRBuf;
         const char *next_img = rbuf + next_slot * kRBuf;
         const f32x4 init_b[2] = {load_init(nhbuf + slot * kBR, 1, 0), load_init(nhbuf + slot * kBR, 1, 1)};
@@ -1522,7 +1524,16 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         init_a[1] = load_init(nhbuf + next_slot * kBR, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk, 0);
-        slot = next_slot;
+    };
+    int chunk = 0;
+    for (; chunk + 3 <= nchunks; chunk += 3) {
+        chunk_body(chunk, std::integral_constant<int, 0>{});
+        chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+        chunk_body(chunk + 2, std::integral_constant<int, 2>{});
+    }
+    if (chunk < nchunks) {
+        chunk_body(chunk, std::integral_constant<int, 0>{});
+        if (chunk + 1 < nchunks) chunk_body(chunk + 1, std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {                                   // second half of the last chunk

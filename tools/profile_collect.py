@@ -48,6 +48,23 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Mean_Value"])
         for key in sorted(agg):
             w.writerow([key[0], key[1], cnt[key], round(agg[key] / cnt[key], 1)])
+# matrix-pipe utilisation per kernel from the SQ passes: SQ_VALU_MFMA_BUSY_CYCLES summed over the chip's 1024 SIMDs
+# against the cycles the kernel lasted (GRBM_GUI_ACTIVE is the sum over the 8 XCDs)
+util = {}
+for f in sorted(glob.glob(os.path.join(dst, f"{rnd}_pmc_*_SQ.csv"))):
+    tag = os.path.basename(f)[len(f"{rnd}_pmc_"):-len("_SQ.csv")]
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        per[r["Kernel_Name"]][r["Counter_Name"]] = float(r["Mean_Value"])
+    for kern, c in per.items():
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            short = kern.split("::")[-1].split("(")[0]
+            util.setdefault(tag, {})[short] = {
+                "mfma_busy_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"], "kernel_cycles": c["GRBM_GUI_ACTIVE"] / 8,
+                "mfma_util": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 4)}
+if util:
+    import json
+    json.dump(util, open(os.path.join(dst, f"{rnd}_pmc_mfma_util.json"), "w"), indent=1, sort_keys=True)
 subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "pmc_summary.py"), src,
                        os.path.join(dst, f"{rnd}_pmc_traffic.json")], stdout=subprocess.DEVNULL)
 bd = os.path.join(src, "bench_default.json")
