@@ -1128,14 +1128,29 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
     const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
     const unsigned lane_off = row_off + st_seg * 16;
     auto stage = [&](int64_t r0, int slot) {
-        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
-        unsigned voff = lane_off;
-        if (!full) voff = row_off + (r0 + st_seg * 8 < rend ? (unsigned)(r0 + st_seg * 8) * 2 : 0);
+        // uniform: only a last chunk can be ragged.  Steady state: the chunk's column offset goes into the lane
+        // offset (one vector add), the scalar bases of the kSeg pieces are loop invariants, m0 = slot base + piece
+        if (__builtin_expect((int)(rend - r0) >= kBR, 1)) {
+            const unsigned col2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)r0 * 2u));   // < 2^28
+            const unsigned v0 = lane_off + col2;
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * kRBuf + wq_u * kSeg * 1024));
+            static_for<0, kSeg>([&](auto ic) {
+                constexpr int e = decltype(ic)::value;
+                const int id = wq_u * kSeg + e;          // rows [8 id, 8 id + 8)
+                uint64_t sbase = (uint64_t)rb + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sbase >> 32));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sbase);
+                sbase = ((uint64_t)hi << 32) | lo;
+                glds_b128_lean<e * 1024>(v0, sbase, sb);
+            });
+        } else {
+            const unsigned voff = row_off + (r0 + st_seg * 8 < rend ? (unsigned)(r0 + st_seg * 8) * 2 : 0);
 #pragma unroll
-        for (int e = 0; e < kSeg; ++e) {
-            const int id = wq_u * kSeg + e;              // rows [8 id, 8 id + 8)
-            const uint64_t sbase = (uint64_t)rb + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
-            glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
+            for (int e = 0; e < kSeg; ++e) {
+                const int id = wq_u * kSeg + e;
+                const uint64_t sbase = (uint64_t)rb + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kRBuf + id * 1024));
+            }
         }
     };
     // norm entry of the chunk after next, parked in a register; the masking is applied when it is
@@ -1159,9 +1174,9 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
         stage(clamp_chunk(1), 1);
-        fetch_nh(clamp_chunk(0));
-        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
-        fetch_nh(clamp_chunk(1));
+        if (wq_u == 0) fetch_nh(clamp_chunk(0));
+        if (wq_u == 0) nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        if (wq_u == 0) fetch_nh(clamp_chunk(1));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1249,11 +1264,11 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
         const f32x16 init_b = load_init(nhbuf + slot * kBR, 1);
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 0, rimg, 1, a0, a1, init_a, acc_a, acc_b, chunk * 2 - 1);
-        nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;   // all waves write the same values
+        if (wq_u == 0) nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;   // one wave stages the norm entries
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ISPA_ABLATE != 2) stage(clamp_chunk(chunk + 2), after_slot);
-        fetch_nh(clamp_chunk(chunk + 2));
+        if (wq_u == 0) fetch_nh(clamp_chunk(chunk + 2));
         init_a = load_init(nhbuf + next_slot * kBR, 0);
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 1, next_img, 0, a0, a1, init_b, acc_b, acc_a, chunk * 2);
