@@ -612,8 +612,8 @@ def main():
     extra = {}
 
     def side_run(fn, n_steps=10):
-        """(elapsed seconds over ranks, mean filter-kernel ms) of n_steps calls of fn, after two warm-up calls."""
-        for _ in range(2):
+        """(elapsed seconds over ranks, mean filter-kernel ms) of n_steps calls of fn, after five warm-up calls."""
+        for _ in range(5):
             fn()
         _abi.check(_abi.lib.ispa_timing_enable(n_steps))
         el = sharding.timed_steps(fn, lambda: None, n_steps, 0, torch.cuda.synchronize)
@@ -624,7 +624,7 @@ def main():
         return el, (float(np.mean(buf[:got.value])) if got.value else float("nan"))
 
     if args.dtype == "f32" and not args.no_extra:
-        n16 = 10
+        n16 = 20
         q16, r16 = q.to(torch.bfloat16), r.to(torch.bfloat16)
         el16, k16 = side_run(lambda: pea.correspondence.dense_nn(q16, r16, args.k), n16)
         tf16 = 2.0 * n * n * c * b / (k16 * 1e-3) / 1e12
