@@ -55,8 +55,8 @@ class PointOrder:
 
     def __init__(self, key_3d, perm=None):
         pts = key_3d.detach().cpu().numpy() if dv.is_tensor(key_3d) else np.asarray(key_3d, dtype=np.float64)
-        if perm is None:
-            perm = run_proj.spatial_order(pts)
+        if perm is None:                             # non-finite coordinates only need SOME place in the order
+            perm = run_proj.spatial_order(np.nan_to_num(pts, nan=0.0, posinf=0.0, neginf=0.0))
         perm = np.asarray(perm, dtype=np.int64)
         if perm.shape != (pts.shape[0],) or not np.array_equal(np.sort(perm), np.arange(pts.shape[0])):
             raise ValueError("perm must be a permutation of the model's point indices")

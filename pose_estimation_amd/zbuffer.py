@@ -27,8 +27,14 @@ def zbuffer(pt_render, size=(540, 960), radius=0, want=("winner", "depth")):
     return {k: dv.back(v, as_tensor) for k, v in out.items()}
 
 
-def project_zbuffer(model_pts, cams, size=(540, 960), radius=0, relax=0.0, want=("packed", "truth"), pt_render=None):
+def project_zbuffer(model_pts, cams, size=(540, 960), radius=0, relax=0.0, want=("packed", "truth"), pt_render=None,
+                    point_order=None):
     """Projection + z-buffer + visibility in one screen-tiled pass (ispa_project_zbuffer).
+
+    point_order: a disparity.PointOrder of model_pts.  The pass then runs on the points in that order (what makes
+    it fast, see below) and the results come back in the order of model_pts: 'truth' columns and 'winner' indices
+    refer to model_pts.  ('packed' keys keep the processing-order index in their low half, and two points of
+    exactly equal float32 depth on one pixel are told apart by processing order, not by their index in model_pts.)
 
     model_pts (N,3), cams (3,4) or (n_pose,3,4); or pt_render=(n_pose,3,N) already projected coordinates
     (ispa_zbuffer_tiled).  `want` picks the outputs: 'packed' u64 keys (as int64), 'winner' int32 (-1 empty),
@@ -38,9 +44,11 @@ def project_zbuffer(model_pts, cams, size=(540, 960), radius=0, relax=0.0, want=
     same for any order, but a tile only skips the chunks of points that project elsewhere when consecutive
     points are neighbours in space."""
     from_render = pt_render is not None
+    if point_order is not None and (from_render or point_order.n != len(model_pts)):
+        raise ValueError("point_order goes with model_pts and must describe them")
     src_in = pt_render if from_render else model_pts
     as_tensor = dv.is_tensor(src_in)
-    src = dv.to_dev(src_in, torch.float64)
+    src = point_order.points if point_order is not None else dv.to_dev(src_in, torch.float64)
     if from_render:
         single = src.dim() == 2
         if single:
@@ -72,6 +80,12 @@ def project_zbuffer(model_pts, cams, size=(540, 960), radius=0, relax=0.0, want=
         _abi.check(_abi.lib.ispa_project_zbuffer(dv.ptr(src), n, dv.ptr(cams_t), n_pose, h, w, int(radius), float(relax),
                                                  dv.ptr(packed), dv.ptr(winner), dv.ptr(depth), dv.ptr(truth),
                                                  dv.ptr(ws), need, dv.stream_ptr()))
+    if point_order is not None:                      # back to the order of model_pts
+        if truth is not None:
+            truth = truth[:, point_order.inverse.long()]
+        if winner is not None:
+            rank = torch.cat([point_order.rank, point_order.rank.new_full((1,), -1)])     # index -1 -> -1
+            winner = rank[winner.long()]
     out = {"packed": packed, "winner": winner, "depth": depth, "truth": None if truth is None else truth.bool()}
     out = {k: (v[0] if single else v) for k, v in out.items() if v is not None}
     return {k: dv.back(v, as_tensor) for k, v in out.items()}

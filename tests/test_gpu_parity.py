@@ -556,6 +556,14 @@ def test_project_zbuffer_tiled_against_oracle(pea):
                 assert np.array_equal(got["winner"][p], win) and np.array_equal(got["depth"][p], depth)
                 assert np.array_equal(got["truth"][p], vis)
             assert got["truth"].sum() > 100
+    # the same results, in the order of the given points, when the pass runs on a processing order of its own
+    po = pea.disparity.PointOrder(pts)
+    plain = pea.zbuffer.project_zbuffer(pts, cams, radius=2, relax=0.01, want=("winner", "depth", "truth"))
+    fast = pea.zbuffer.project_zbuffer(pts, cams, radius=2, relax=0.01, want=("winner", "depth", "truth"), point_order=po)
+    for key in ("winner", "depth", "truth"):
+        assert np.array_equal(plain[key], fast[key]), key
+    with pytest.raises(ValueError):
+        pea.zbuffer.project_zbuffer(pts[:-1], cams, point_order=po)
     # flags only, one camera, no images written
     only = pea.zbuffer.project_zbuffer(pts, cams[0], want=("truth",))
     assert set(only) == {"truth"} and np.array_equal(only["truth"], _zb_oracle(pts, cams[0], 540, 960, 0, 0.0)[4])
