@@ -315,6 +315,19 @@ int ispa_pck_counts(const int32_t *ind, int B, int k, int64_t n, const double *c
                     double downsampling, int index_base, const double *radii, int n_radii,
                     int32_t *counts, void *stream);
 
+/* HardNegativeProcessingLayer.forward, which correspondences are hard negatives
+ *   ucn_code/lib/layers/hard_negative_processing_layer.py:188-192 (coordinates), :246-250 (the test);
+ *   threshold cfg.NEGATIVE_MINING_PIXEL_THRESH = 4 feature cells (ucn_code/lib/config.py:80)
+ * ind, correspondences, width, downsampling, index_base as for ispa_pck_counts.
+ * mask (B,n) u8 = 1 where the row is valid (flag == 1) and its nearest cell (x, y) lies farther than thresh from
+ * the ground truth in FEATURE coordinates, (x2, y2) / downsampling; knn_xy (optional, may be NULL) (B,n,2) f64 =
+ * the nearest cell's image coordinate (x, y) * downsampling, which the layer writes over a negative pair's
+ * columns 2:4 (:265).  Which random negatives get overwritten (:254-266) draws from numpy's global random
+ * stream and stays with the caller. */
+int ispa_hard_negatives(const int32_t *ind, int B, int k, int64_t n, const double *correspondences, int width,
+                        double downsampling, int index_base, double thresh, uint8_t *mask, double *knn_xy,
+                        void *stream);
+
 /* Pruning of dense 2-D skeleton keypoints on annotated real images, batched over images
  *   data_creator/utils.py:274-290 (surface_pruned), :292-325 (dir_pruned), :327-348 (surface_dir_prune);
  *   caller data_creator/make_dense_pointset.py:91-95

@@ -200,3 +200,21 @@ def pck_counts(knn_inds_one_based, correspondences, width, radii, downsampling=4
         for i, rad in enumerate(radii):
             out[i, n] = np.sum(d < rad)
     return out
+
+
+def hard_negatives(knn_inds_one_based, correspondences, width, thresh=4, downsampling=4):
+    """hard_negative_processing_layer.py:188-192,246-250: per valid ground-truth correspondence (flag column 4 ==
+    1), whether its 1-NN lies farther than `thresh` from the ground truth in FEATURE coordinates
+    (cfg.NEGATIVE_MINING_PIXEL_THRESH, ucn_code/lib/config.py:80), and the image coordinate of every row's 1-NN
+    (line 189).  Returns (mask (B,n) bool, False on rows that are not valid; knn_xy (B,n,2))."""
+    knn = np.asarray(knn_inds_one_based)
+    corr = np.asarray(correspondences)
+    feat_knn = ind2coord(knn, width, 1)                       # (B, k, n, 2) feature coordinates
+    img_knn = feat_knn * downsampling                         # _transform_coord_feat2im
+    feat_gt = corr[:, :, 2:4] / downsampling                  # _transform_coord_im2feat
+    mask = np.zeros(corr.shape[:2], dtype=bool)
+    for n in range(corr.shape[0]):
+        ones = corr[n, :, 4] == 1
+        feat_dist = np.sqrt(np.sum((feat_knn[n, 0, ones] - feat_gt[n, ones]) ** 2, axis=1))
+        mask[n, ones] = feat_dist > thresh
+    return mask, img_knn[:, 0]

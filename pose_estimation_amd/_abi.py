@@ -68,6 +68,7 @@ SIGNATURES = {
     "ispa_extract_feature": (_i, [_p, _i, _i, _i, _i, _p, _i64, _i, _i, ctypes.c_float, _i, _p, _p]),
     "ispa_nearest_view": (_i, [_p, _i, _p, _i, _p, _p, _p]),
     "ispa_pck_counts": (_i, [_p, _i, _i, _i64, _p, _i, _d, _i, _p, _i, _p, _p]),
+    "ispa_hard_negatives": (_i, [_p, _i, _i, _i64, _p, _i, _d, _i, _d, _p, _p, _p]),
     "ispa_prune_points_2d": (_i, [_p, _i, _i64, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
 }
 

@@ -3,6 +3,7 @@
   dense_nn                 the `KNN` layer contract of ucn_code/nets/train.prototxt:2116-2141
   l2norm                   ucn_code/lib/layers/l2norm_layer.py:18-29
   ind2coord, pck           ucn_code/lib/layers/hard_negative_processing_layer.py:44-58,188-190,218-234
+  hard_negatives           ucn_code/lib/layers/hard_negative_processing_layer.py:188-192,246-250
   CorrelationMapLayer      classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py:161-231
   correlation_map_acmm     classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py:33-61
   get_pt, knn_inds_to_grid classifier_code/train_test_scripts/utils/proxy_renderer.py:50-58 and
@@ -152,6 +153,33 @@ def pck(ind, correspondences, width, radii, downsampling_factor=4, index_base=1)
     _abi.check(_abi.lib.ispa_pck_counts(dv.ptr(it), b, k, n, dv.ptr(ct), int(width), float(downsampling_factor),
                                         int(index_base), dv.ptr(rt), len(radii), dv.ptr(counts), dv.stream_ptr()))
     return dv.back(counts.to(torch.float64), as_tensor)
+
+
+NEGATIVE_MINING_PIXEL_THRESH = 4      # ucn_code/lib/config.py:80
+
+
+def hard_negatives(ind, correspondences, width, thresh=NEGATIVE_MINING_PIXEL_THRESH, downsampling_factor=4,
+                   index_base=1):
+    """Which ground-truth correspondences the 1-NN search got wrong by more than `thresh` feature cells, as
+    HardNegativeProcessingLayer.forward decides it (hard_negative_processing_layer.py:188-192,246-250), on the
+    device (ispa_hard_negatives).
+
+    ind (B,k,n) from dense_nn; correspondences (B,n,5) rows [x1, y1, x2, y2, flag].  Returns (mask (B,n) bool,
+    knn_xy (B,n,2) float64): mask[b,i] is True where flag == 1 and the nearest cell is farther than thresh from
+    (x2, y2) / downsampling_factor; knn_xy is the nearest cell's image coordinate, what the layer writes into
+    columns 2:4 of the negative pairs it overwrites (line 265; the random choice of those pairs, lines 254-266,
+    is the caller's).  The layer's `hard_neg_inds` is mask[b][flag == 1]."""
+    as_tensor = dv.is_tensor(ind)
+    it = dv.to_dev(ind, torch.int32)
+    ct = dv.to_dev(correspondences, torch.float64)
+    if it.dim() != 3 or ct.dim() != 3 or ct.shape[2] != 5 or ct.shape[:2] != (it.shape[0], it.shape[2]):
+        raise ValueError("ind must be (B,k,n) and correspondences (B,n,5)")
+    b, k, n = it.shape
+    mask = dv.empty((b, n), torch.uint8)
+    xy = dv.empty((b, n, 2), torch.float64)
+    _abi.check(_abi.lib.ispa_hard_negatives(dv.ptr(it), b, k, n, dv.ptr(ct), int(width), float(downsampling_factor),
+                                            int(index_base), float(thresh), dv.ptr(mask), dv.ptr(xy), dv.stream_ptr()))
+    return dv.back(mask.bool(), as_tensor), dv.back(xy, as_tensor)
 
 
 def resize_bilinear(x, size):

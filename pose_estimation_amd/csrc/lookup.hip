@@ -101,6 +101,31 @@ __global__ __launch_bounds__(kThreads) void pck_counts_kernel(const int32_t *__r
     if (threadIdx.x < n_radii) counts[threadIdx.x * B + b] = hits[threadIdx.x];
 }
 
+// Per correspondence row: is the 1-NN a hard negative (a valid row whose nearest cell lies farther than `thresh`
+// FEATURE cells from the ground truth), and the image coordinate of that nearest cell.  numpy's order of operations:
+// ground truth / downsampling, differences, squares added left to right, correctly rounded sqrt.
+__global__ __launch_bounds__(kThreads) void hard_negative_kernel(const int32_t *__restrict__ ind, int k, int64_t n,
+                                                                  const double *__restrict__ corr, int width,
+                                                                  double downsampling, int index_base, double thresh,
+                                                                  uint8_t *__restrict__ mask, double *__restrict__ knn_xy) {
+    const int b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const double *c = corr + ((int64_t)b * n + i) * 5;
+    const int j = ind[(int64_t)b * k * n + i] - index_base;              // nearest neighbour = row 0 of k
+    int x = j % width;
+    if (x < 0) x += width;
+    const double y = floor((double)j / (double)width);
+    const double dx = (double)x - c[2] / downsampling;
+    const double dy = y - c[3] / downsampling;
+    const double dist = sqrt(dx * dx + dy * dy);
+    mask[(int64_t)b * n + i] = (c[4] == 1.0) && dist > thresh;
+    if (knn_xy) {
+        double2 *o = reinterpret_cast<double2 *>(knn_xy) + (int64_t)b * n + i;
+        *o = make_double2((double)x * downsampling, y * downsampling);
+    }
+}
+
 // out[b][c][i] = feature[b][c] sampled at (x, y) = coords[b][i][start .. start+1] / downsampling.
 // One thread per (b, i); the channel loop walks a column of the (C, H*W) map (stride H*W), the
 // stores of a wave are contiguous along i.
@@ -177,4 +202,19 @@ extern "C" int ispa_pck_counts(const int32_t *ind, int B, int k, int64_t n, cons
     hipLaunchKernelGGL(pck_counts_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, ind, k, n, correspondences,
                        width, downsampling, index_base, radii, n_radii, B, counts);
     return ispa::check_launch("pck_counts_kernel");
+}
+
+extern "C" int ispa_hard_negatives(const int32_t *ind, int B, int k, int64_t n, const double *correspondences, int width,
+                                   double downsampling, int index_base, double thresh, uint8_t *mask, double *knn_xy,
+                                   void *stream) {
+    ISPA_REQUIRE(B >= 0 && n >= 0, "negative size");
+    ISPA_REQUIRE(k >= 1 && width >= 1, "k (%d) and width (%d) must be positive", k, width);
+    ISPA_REQUIRE(downsampling > 0.0, "downsampling factor must be positive");
+    if (B == 0 || n == 0) return ISPA_OK;
+    ISPA_REQUIRE(B <= 65535, "too many batch items per call (%d)", B);
+    ISPA_REQUIRE(ind && correspondences && mask, "null pointer");
+    hipLaunchKernelGGL(hard_negative_kernel, dim3(ispa::blocks_for(n, kThreads), B), dim3(kThreads), 0,
+                       (hipStream_t)stream, ind, k, n, correspondences, width, downsampling, index_base, thresh, mask,
+                       knn_xy);
+    return ispa::check_launch("hard_negative_kernel");
 }

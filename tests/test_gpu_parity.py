@@ -1195,6 +1195,38 @@ def test_pck_counts_match_numpy(pea):
         pea.correspondence.pck(ind, corr, width, list(range(1, 10)))
 
 
+def test_hard_negatives_match_numpy(pea):
+    import torch
+    rs = np.random.RandomState(29)
+    b, k, n, width = 3, 2, 900, 56
+    ind = rs.randint(1, width * width + 1, (b, k, n)).astype(np.int32)
+    corr = np.concatenate([rs.uniform(0, 224, (b, n, 4)), rs.choice([1.0, 0.0, -1.0], (b, n, 1))], axis=2)
+    cell = okp.ind2coord(ind[:, 0, :], width, 1)                            # feature coordinates of the 1-NN
+    corr[:, :60, 2:4] = (cell[:, :60] + rs.uniform(-6, 6, (b, 60, 2))) * 4  # around the threshold
+    corr[:, 60:70, 2:4] = (cell[:, 60:70] + [0.0, 4.0]) * 4                 # distance exactly 4: not > 4
+    corr[:, 70:80, 2:4] = cell[:, 70:80] * 4                                # distance 0
+    corr[:, :80, 4] = 1.0
+    want_mask, want_xy = okp.hard_negatives(ind, corr, width)
+    mask, xy = pea.correspondence.hard_negatives(ind, corr, width)
+    assert mask.dtype == np.bool_ and np.array_equal(mask, want_mask) and np.array_equal(xy, want_xy)
+    assert 10 < want_mask[:, :60].sum() < 170 and not want_mask[:, 60:80].any()
+    assert not mask[corr[:, :, 4] != 1].any()
+    # zero-based device tensors, another threshold and stride
+    m0, xy0 = pea.correspondence.hard_negatives(torch.from_numpy(ind - 1).cuda(), torch.from_numpy(corr).cuda(), width,
+                                                thresh=2.5, downsampling_factor=8, index_base=0)
+    wm, wxy = okp.hard_negatives(ind, corr, width, thresh=2.5, downsampling=8)
+    assert torch.is_tensor(m0) and np.array_equal(m0.cpu().numpy(), wm) and np.array_equal(xy0.cpu().numpy(), wxy)
+    # straight from dense_nn; the layer's hard_neg_inds = mask[flag == 1]
+    q, r = _unit(rs, (2, 32, 56 * 56)), _unit(rs, (2, 32, 56 * 56))
+    _, nn = pea.correspondence.dense_nn(q, r, 1)
+    c2 = np.concatenate([rs.uniform(0, 224, (2, 56 * 56, 4)), np.ones((2, 56 * 56, 1))], axis=2)
+    got = pea.correspondence.hard_negatives(nn, c2, 56)
+    want = okp.hard_negatives(nn, c2, 56)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and want[0].mean() > 0.9
+    with pytest.raises(ValueError):
+        pea.correspondence.hard_negatives(ind, corr[:, :-1], width)
+
+
 # ---------------------------------------------------------------- correlation maps
 def test_corr_eccv_views_equals_the_per_view_loop(pea):
     rs = np.random.RandomState(61)
