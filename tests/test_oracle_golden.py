@@ -389,3 +389,17 @@ def test_exr_reader_on_the_blender_render_and_round_trips(tmp_path):
         exr.read_exr_channel(str(tmp_path / "layer.exr"), "Z")
     with pytest.raises(ValueError):
         exr.read_exr(b"not an exr file at all")
+
+
+def test_hard_negative_rule_by_hand():
+    """hard_negative_processing_layer.py:188-192,246-250 on a 4-cell-wide map: 1-based indices 6, 1, 16, 11 are
+    the cells (1,1), (0,0), (3,3), (2,2); ground truth in image pixels (stride 4); threshold 4 feature cells."""
+    ind = np.array([[[6, 1, 16, 11]]])
+    corr = np.array([[[0, 0, 4.0, 4.0, 1],        # on its cell: distance 0
+                      [0, 0, 0.0, 16.0, 1],       # (0,0) against (0,4): exactly 4, not a hard negative
+                      [0, 0, 0.0, 0.0, 1],        # (3,3) against (0,0): sqrt(18) > 4
+                      [0, 0, 40.0, 40.0, 0]]])    # far off, but not a positive pair (flag 0)
+    mask, xy = kp.hard_negatives(ind, corr, 4)
+    assert mask.tolist() == [[False, False, True, False]]
+    assert np.array_equal(xy[0], [[4, 4], [0, 0], [12, 12], [8, 8]])
+    assert kp.hard_negatives(ind, corr, 4, thresh=3.9)[0].tolist() == [[False, True, True, False]]
