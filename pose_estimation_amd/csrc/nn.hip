@@ -1700,37 +1700,51 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
     const unsigned row_off = (unsigned)((int64_t)(lane >> 3) * nr * 2);        // bytes; nr < 2^27 on this path
     const unsigned lane_off[2] = {row_off + perm_seg(lane, 0) * 16, row_off + perm_seg(lane, 1) * 16};
     auto stage = [&](int64_t r0, int slot) {
-        const bool full = r0 + kBR <= rend;              // uniform: only a last chunk can be ragged
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const uint16_t *img = (part ? rlo : rhi) + roff;
-#pragma unroll
-            for (int e = 0; e < kPerWave; ++e) {
+        // uniform: only a last chunk can be ragged.  Steady state: the chunk's column offset goes into the lane
+        // offsets, the scalar bases of the pieces are loop invariants, m0 = slot base + piece offset
+        if (__builtin_expect((int)(rend - r0) >= kBR, 1)) {
+            const unsigned col2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)r0 * 2u));   // < 2^28
+            const unsigned v0 = lane_off[0] + col2, v1 = lane_off[1] + col2;
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * kSlot + wq_u * kPerWave * 1024));
+            static_for<0, 2 * kPerWave>([&](auto ic) {
+                constexpr int part = decltype(ic)::value / kPerWave, e = decltype(ic)::value % kPerWave;
                 const int id = wq_u * kPerWave + e;                        // rows [8 id, 8 id + 8)
-                unsigned voff = lane_off[id & 1];
-                if (!full) {
+                uint64_t sbase = (uint64_t)((part ? rlo : rhi) + roff) + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sbase >> 32));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sbase);
+                sbase = ((uint64_t)hi << 32) | lo;
+                glds_b128_lean<part * kImg + e * 1024>((id & 1) ? v1 : v0, sbase, sb);
+            });
+        } else {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint16_t *img = (part ? rlo : rhi) + roff;
+#pragma unroll
+                for (int e = 0; e < kPerWave; ++e) {
+                    const int id = wq_u * kPerWave + e;
                     const int64_t col = r0 + perm_seg(lane, id & 1) * 8;
-                    voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+                    const unsigned voff = row_off + (col < rend ? (unsigned)col * 2 : 0);
+                    const uint64_t sbase = (uint64_t)img + (uint64_t)(8 * id) * (uint64_t)nr * 2u;
+                    glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kSlot + part * kImg + id * 1024));
                 }
-                const uint64_t sbase =
-                    (uint64_t)img + ((uint64_t)(8 * id) * (uint64_t)nr + (uint64_t)(full ? r0 : 0)) * 2u;
-                glds_b128(voff, sbase, __builtin_amdgcn_readfirstlane(lds_base + slot * kSlot + part * kImg + id * 1024));
             }
         }
     };
     float pre_nh = 0.f;
     bool pre_ok = false;
+    const int nh_lane = tid & (kBR - 1);
     auto fetch_nh = [&](int64_t r0) {
-        pre_ok = r0 + (tid & (kBR - 1)) < rend;
-        pre_nh = nhb[pre_ok ? r0 + (tid & (kBR - 1)) : 0];
+        const int left = (int)(rend - r0);               // 32-bit lane arithmetic on a uniform base
+        pre_ok = nh_lane < left;
+        pre_nh = (nhb + r0)[pre_ok ? nh_lane : 0];
     };
     auto clamp_chunk = [&](int c) { return rbeg + (int64_t)(c < nchunks ? c : nchunks - 1) * kBR; };
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
         stage(clamp_chunk(1), 1);
-        fetch_nh(clamp_chunk(0));
-        nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
-        fetch_nh(clamp_chunk(1));
+        if (wq_u == 0) fetch_nh(clamp_chunk(0));        // one wave stages the norm entries
+        if (wq_u == 0) nhbuf[tid & (kBR - 1)] = pre_ok ? pre_nh : kNegInf;
+        if (wq_u == 0) fetch_nh(clamp_chunk(1));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1817,8 +1831,10 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
         }
     };
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int slot = chunk & 1;
+    // one chunk in ring slot `slot`, a compile-time constant (the loop is unrolled over the two slots: LDS
+    // addresses are loop-invariant lane registers plus immediates, the staging's m0 values constants)
+    auto chunk_body = [&](int chunk, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
         const char *img = ring + slot * kSlot;
         const float *nh = nhbuf + slot * kBR;
         const f32x4 init_a[2] = {load_init(nh, 0, 0), load_init(nh, 0, 1)};
@@ -1827,12 +1843,18 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
         half_step(img, 1, init_b, acc_b, acc_a, chunk, 0);
         // chunk end: the next chunk's images (requested a chunk ago) must have landed, and this slot
         // must be free of readers before it is refilled
-        nhbuf[(slot ^ 1) * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
+        if (wq_u == 0) nhbuf[(slot ^ 1) * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stage(clamp_chunk(chunk + 2), slot);
-        fetch_nh(clamp_chunk(chunk + 2));
+        if (wq_u == 0) fetch_nh(clamp_chunk(chunk + 2));
+    };
+    int chunk = 0;
+    for (; chunk + 2 <= nchunks; chunk += 2) {
+        chunk_body(chunk, std::integral_constant<int, 0>{});
+        chunk_body(chunk + 1, std::integral_constant<int, 1>{});
     }
+    if (chunk < nchunks) chunk_body(chunk, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll
