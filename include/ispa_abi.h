@@ -237,10 +237,9 @@ int ispa_nn_topk_noalloc(const void *q, const void *r, int dtype, int B, int C, 
 
 /* Measurement hooks (no counterpart in the reference).  After ispa_timing_enable(n), each of the
  * next n calls of ispa_nn_topk (its filter kernel, the launch that does the MFMA contraction),
- * ispa_project, ispa_project_prune, ispa_flow_splat, ispa_make_disparity, ispa_zbuffer or
- * ispa_corr_map_eccv / ispa_corr_map_acmm brackets its dominant
- * kernel with HIP events
- * on the call's stream.  ispa_timing_collect waits for
+ * ispa_project, ispa_project_prune, ispa_flow_splat (square maps up to 448 pixels a side), ispa_make_disparity /
+ * _ws / _ordered (both launches of the latter two as one record), ispa_zbuffer, ispa_project_zbuffer or
+ * ispa_corr_map_eccv / ispa_corr_map_acmm brackets its dominant kernel with HIP events on the call's stream.  ispa_timing_collect waits for
  * them, writes the elapsed milliseconds of the recorded calls to a HOST array and re-arms the
  * slots.  ispa_timing_enable(0) turns it off and releases the events.  Not thread-safe. */
 int ispa_timing_enable(int max_records);
