@@ -2585,10 +2585,11 @@ __global__ __launch_bounds__(NT) void nn_exact_kernel(const T *__restrict__ q, c
 #pragma unroll
                 for (int u = 0; u < V; ++u) dot[u] = 0.0;
                 const T *rp = rb + j0;
-#pragma unroll 4
-                for (int c = 0; c < C; ++c) {
-                    const double qv = qs[c];
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(rp + (int64_t)c * nr);
+                // kDepth channel rows are requested before the first of them is used (the scheduling barriers pin
+                // that order: left alone, the compiler issues one load, waits for it, uses it, and a thread's sweep
+                // becomes a chain of C memory latencies, about 1400 cycles each from the Infinity Cache / HBM)
+                constexpr int kDepth = 8;
+                auto use = [&](const uint4 &raw, double qv) {
                     const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
                     for (int u = 0; u < V; ++u) {
@@ -2599,7 +2600,19 @@ __global__ __launch_bounds__(NT) void nn_exact_kernel(const T *__restrict__ q, c
                             rv = __uint_as_float((u & 1) ? (w[u >> 1] & 0xffff0000u) : (w[u >> 1] << 16));
                         dot[u] = fma(qv, (double)rv, dot[u]);
                     }
+                };
+                int c0 = 0;
+                for (; c0 + kDepth <= C; c0 += kDepth) {
+                    uint4 raw[kDepth];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < kDepth; ++e)
+                        raw[e] = *reinterpret_cast<const uint4 *>(rp + (int64_t)(c0 + e) * nr);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < kDepth; ++e) use(raw[e], qs[c0 + e]);
                 }
+                for (; c0 < C; ++c0) use(*reinterpret_cast<const uint4 *>(rp + (int64_t)c0 * nr), qs[c0]);
 #pragma unroll
                 for (int u = 0; u < V; ++u) consider(dot[u], (int)(j0 + u));
             }
