@@ -2722,16 +2722,15 @@ __global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict_
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dot[qi][u] = 0.0;
             const T *rp = rb + j0;
-            for (int c = 0; c < C; ++c) {
+            using Raw = typename std::conditional<sizeof(T) == 4, float4, uint2>::type;
+            auto use = [&](const Raw &raw, int c) {
                 float rv[4];
-                if (sizeof(T) == 4) {
-                    const float4 raw = *reinterpret_cast<const float4 *>(rp + (int64_t)c * nr);
+                if constexpr (sizeof(T) == 4) {
                     rv[0] = raw.x;
                     rv[1] = raw.y;
                     rv[2] = raw.z;
                     rv[3] = raw.w;
                 } else {
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(rp + (int64_t)c * nr);
                     rv[0] = __uint_as_float(raw.x << 16);
                     rv[1] = __uint_as_float(raw.x & 0xffff0000u);
                     rv[2] = __uint_as_float(raw.y << 16);
@@ -2743,7 +2742,23 @@ __global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict_
 #pragma unroll
                     for (int u = 0; u < 4; ++u) dot[qi][u] = fma(qv, (double)rv[u], dot[qi][u]);
                 }
+            };
+            // Full batches without control flow inside: all rows of a batch are requested before
+            // the first is used, and the scheduling barriers keep the compiler from folding the
+            // batch back into load - wait - use.
+            constexpr int kDepth = 8;
+            int c0 = 0;
+            for (; c0 + kDepth <= C; c0 += kDepth) {
+                Raw raw[kDepth];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < kDepth; ++e)
+                    raw[e] = *reinterpret_cast<const Raw *>(rp + (int64_t)(c0 + e) * nr);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < kDepth; ++e) use(raw[e], c0 + e);
             }
+            for (; c0 < C; ++c0) use(*reinterpret_cast<const Raw *>(rp + (int64_t)c0 * nr), c0);
 #pragma unroll
             for (int qi = 0; qi < kQB; ++qi) {
                 const int64_t i = pair_list[(int64_t)b * nq + base + (qi < nqry ? qi : 0)];
