@@ -2220,10 +2220,11 @@ __global__ __launch_bounds__(256) void nn_rescore_topk_kernel(const float *__res
 //   64-byte sector per (entry, channel).
 // Channel order is increasing either way, so both routes return the float64 pass's bits.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRefineThreads = 1024;
+// Two workgroups share a CU (64 KB of LDS each), so one's staging overlaps the other's gathers.
+constexpr int kRefineThreads = 512;
 constexpr int kRefinePer = 8;                                   // entries per thread
 constexpr int kRefineEntries = kRefineThreads * kRefinePer;
-constexpr int kRefineLds = 128 * 1024;
+constexpr int kRefineLds = 64 * 1024;
 
 template <typename T>
 __global__ __launch_bounds__(kRefineThreads) void nn_refine_kernel(const T *__restrict__ q, const T *__restrict__ r,
@@ -2282,33 +2283,46 @@ __global__ __launch_bounds__(kRefineThreads) void nn_refine_kernel(const T *__re
     }
     T *tile = reinterpret_cast<T *>(refine_lds);
     constexpr int kVec = 16 / (int)sizeof(T);
+    int rc[kRefinePer];
+#pragma unroll
+    for (int u = 0; u < kRefinePer; ++u) rc[u] = rj[u] < 0 ? 0 : rj[u];
     for (int c0 = 0; c0 < C; c0 += group) {
         const int nc = C - c0 < group ? C - c0 : group;
         __syncthreads();                                        // the previous group has been consumed
         if (vec_ok) {                                           // rows of nr elements, 16-byte aligned
             const int64_t vrow = nr / kVec;
-            for (int64_t t = threadIdx.x; t < vrow * nc; t += kRefineThreads) {
-                const int cc = (int)(t / vrow);
-                const int64_t x = t - cc * vrow;
-                *reinterpret_cast<uint4 *>(tile + cc * row + x * kVec) =
-                    *reinterpret_cast<const uint4 *>(rb + (int64_t)(c0 + cc) * nr + x * kVec);
-            }
+            for (int cc = 0; cc < nc; ++cc)
+                for (int64_t x = threadIdx.x; x < vrow; x += kRefineThreads)
+                    *reinterpret_cast<uint4 *>(tile + cc * row + x * kVec) =
+                        *reinterpret_cast<const uint4 *>(rb + (int64_t)(c0 + cc) * nr + x * kVec);
         } else {
-            for (int64_t t = threadIdx.x; t < nr * nc; t += kRefineThreads) {
-                const int cc = (int)(t / nr);
-                const int64_t x = t - cc * nr;
-                tile[cc * row + x] = rb[(int64_t)(c0 + cc) * nr + x];
-            }
+            for (int cc = 0; cc < nc; ++cc)
+                for (int64_t x = threadIdx.x; x < nr; x += kRefineThreads)
+                    tile[cc * row + x] = rb[(int64_t)(c0 + cc) * nr + x];
         }
         __syncthreads();
-        for (int cc = 0; cc < nc; ++cc) {
-            float qv[kRefinePer];
+        // Unmarked entries gather cell 0 (and query 0) and are dropped at the end: without branches in
+        // the loop two channels' loads are in flight before the first product.
+        auto channels = [&](int cc, auto count) {
+            constexpr int kN = decltype(count)::value;
+            float qv[kN][kRefinePer], rv[kN][kRefinePer];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kRefinePer; ++u) qv[u] = load_as_float(qb + (int64_t)(c0 + cc) * nq + qi[u]);
+            for (int e = 0; e < kN; ++e)
 #pragma unroll
-            for (int u = 0; u < kRefinePer; ++u)
-                if (rj[u] >= 0) dot[u] = fma((double)qv[u], (double)load_as_float(tile + cc * row + rj[u]), dot[u]);
-        }
+                for (int u = 0; u < kRefinePer; ++u) {
+                    qv[e][u] = load_as_float(qb + (int64_t)(c0 + cc + e) * nq + qi[u]);
+                    rv[e][u] = load_as_float(tile + (cc + e) * row + rc[u]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < kN; ++e)
+#pragma unroll
+                for (int u = 0; u < kRefinePer; ++u) dot[u] = fma((double)qv[e][u], (double)rv[e][u], dot[u]);
+        };
+        int cc = 0;
+        for (; cc + 2 <= nc; cc += 2) channels(cc, std::integral_constant<int, 2>{});
+        for (; cc < nc; ++cc) channels(cc, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int u = 0; u < kRefinePer; ++u)
