@@ -2708,12 +2708,14 @@ __global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict_
     double *qs = reinterpret_cast<double *>(smem);                 // [kQB][C]
     double *sd = qs + kQB * C;                                     // 256
     int *sj = reinterpret_cast<int *>(sd + 256);                   // 256
-    const int b = blockIdx.y;
+    // The pair index runs fastest over the grid: workgroups go to the eight XCDs in turn by linear index, and
+    // with the batch slot fastest the busy ones (a pair's first slots) would land on every second XCD only.
+    const int b = blockIdx.x;
     const int count = pair_count[b];
-    if (count < kBatchMin || *total_count < kBatchMin * (int)gridDim.y) return;
+    if (count < kBatchMin || *total_count < kBatchMin * (int)gridDim.x) return;
     const T *rb = r + (int64_t)b * C * nr;
     const double *rrb = rr64 + (int64_t)b * nr;
-    for (int base = blockIdx.x * kQB; base < count; base += gridDim.x * kQB) {
+    for (int base = blockIdx.y * kQB; base < count; base += gridDim.y * kQB) {
         const int nqry = min(kQB, count - base);
         __syncthreads();
         for (int t = threadIdx.x; t < kQB * C; t += 256) {
@@ -2757,20 +2759,38 @@ __global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict_
                     for (int u = 0; u < 4; ++u) dot[qi][u] = fma(qv, (double)rv[u], dot[qi][u]);
                 }
             };
-            // Full batches without control flow inside: all rows of a batch are requested before
-            // the first is used, and the scheduling barriers keep the compiler from folding the
-            // batch back into load - wait - use.
-            constexpr int kDepth = 8;
+            // Batches of kDepth channel rows, two buffers: the rows of the next batch are requested before the
+            // products of the current one start, and the scheduling barriers keep the compiler from folding
+            // that back into load - wait - use.  No control flow inside a batch; a batch past the end re-reads
+            // the last row and is never used.
+            constexpr int kDepth = sizeof(T) == 4 ? 4 : 8;      // 64 bytes per buffer: two waves per SIMD still fit
+            auto load = [&](Raw(&dst)[kDepth], int cb) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < kDepth; ++e) {
+                    const int c = cb + e < C ? cb + e : C - 1;
+                    dst[e] = *reinterpret_cast<const Raw *>(rp + (int64_t)c * nr);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto use_batch = [&](const Raw(&src)[kDepth], int cb) {
+#pragma unroll
+                for (int e = 0; e < kDepth; ++e) use(src[e], cb + e);
+            };
+            const int nb = C / kDepth;
             int c0 = 0;
-            for (; c0 + kDepth <= C; c0 += kDepth) {
-                Raw raw[kDepth];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < kDepth; ++e)
-                    raw[e] = *reinterpret_cast<const Raw *>(rp + (int64_t)(c0 + e) * nr);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < kDepth; ++e) use(raw[e], c0 + e);
+            if (nb > 0) {
+                Raw even[kDepth], odd[kDepth];
+                load(even, 0);
+                int i = 0;
+                for (; i + 2 <= nb; i += 2) {
+                    load(odd, (i + 1) * kDepth);
+                    use_batch(even, i * kDepth);
+                    load(even, (i + 2) * kDepth);
+                    use_batch(odd, (i + 1) * kDepth);
+                }
+                if (i < nb) use_batch(even, i * kDepth);
+                c0 = nb * kDepth;
             }
             for (; c0 < C; ++c0) use(*reinterpret_cast<const Raw *>(rp + (int64_t)c0 * nr), c0);
 #pragma unroll
@@ -3187,7 +3207,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         int per_pair = (int)(2048 / B);
         per_pair = per_pair < 4 ? 4 : (per_pair > 64 ? 64 : per_pair);
         const size_t esmem = (size_t)kQB * C * sizeof(double) + 256 * (sizeof(double) + sizeof(int));
-        hipLaunchKernelGGL((nn_exact_top1_kernel<T>), dim3(per_pair, B), dim3(256), esmem, s, q, r, q64, r64, C, nq,
+        hipLaunchKernelGGL((nn_exact_top1_kernel<T>), dim3(B, per_pair), dim3(256), esmem, s, q, r, q64, r64, C, nq,
                            nr, index_base, count, pcount, plist, dist, idx);
         if (int rc = ispa::check_launch("nn_exact_top1_kernel")) return rc;
     }
