@@ -2211,7 +2211,7 @@ __global__ __launch_bounds__(256) void nn_rescore_topk_kernel(const float *__res
 
 // ---------------------------------------------------------------------------------------------
 // 3d. distances of close matches.  nn_finalize_kernel marks the entries whose filter score cannot give
-// the distance to 1e-4 relative; here they are recomputed in float64 (exact_d2).  One 1024-thread block
+// the distance to 1e-4 relative; here they are recomputed in float64 (exact_d2).  One 512-thread block
 // per (slice of kRefineEntries result entries, pair); entry e = s * nq + i is neighbour s of query i.
 //   few marked entries in the slice: each is re-scored straight from global memory (C scattered loads);
 //   many (good matches everywhere, the realistic case for corresponding images): the pair's reference map
