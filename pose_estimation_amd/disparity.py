@@ -7,6 +7,7 @@ of data_creator/render_wt_pt_proj/get_of.py:38-62 (render resolution, no crop, b
 truths).
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -154,22 +155,35 @@ def demo_flow(key_3d, params, depth_maps, step=DEMO_STEP, spread=SPREAD):
     return dv.back(flow, as_tensor)
 
 
-def make_disparity(class_name, key_3d, image_dir, depth_dir, save_dir, template_model, batch=64):
+def make_disparity(class_name, key_3d, image_dir, depth_dir, save_dir, template_model, batch=64, io_threads=8):
     """make_disparity_syn.py:17-70 with the data locations passed in instead of read from
     global_variables: for every render of `template_model` under image_dir, write
-    <save_dir>/<image stem>.npy = (224,224,2) float64 flow.  Returns the number of maps written."""
+    <save_dir>/<image stem>.npy = (224,224,2) float64 flow.  Returns the number of maps written.
+
+    The files either side of the GPU call move on `io_threads` host threads: the depth images of the next batch
+    are decoded while the current one is on the GPU, and the .npy files are written behind it (the script reads,
+    computes and writes one render at a time).  File names and contents are those of the script."""
     del class_name
     os.makedirs(save_dir, exist_ok=True)
     images = sorted(x for x in os.listdir(image_dir) if template_model in x)
     order = PointOrder(key_3d)                       # once per model; every batch of renders re-uses it
-    for start in range(0, len(images), batch):
-        chunk = images[start:start + batch]
-        dicts = [io_utils.get_params_from_syn_file(x) for x in chunk]
-        params = [[d["azimuth"], d["elevation"], d["tilt"], d["rho"]] for d in dicts]
-        crops = [d["crop_params"] for d in dicts]
-        depth = np.stack([run_proj.get_depthmap_from_exr(os.path.join(depth_dir, io_utils.img_to_depth_file(x)))
-                          for x in chunk])
-        flows = make_disparity_maps(key_3d, params, depth, crops, point_order=order)
-        for name, flow in zip(chunk, flows):
-            np.save(os.path.join(save_dir, name.split(".")[0]), flow)
+    chunks = [images[start:start + batch] for start in range(0, len(images), batch)]
+
+    def read_depth(name):
+        return run_proj.get_depthmap_from_exr(os.path.join(depth_dir, io_utils.img_to_depth_file(name)))
+
+    with ThreadPoolExecutor(max_workers=max(1, int(io_threads))) as pool:
+        reads = [pool.submit(read_depth, x) for x in chunks[0]] if chunks else []
+        writes = []
+        for n, chunk in enumerate(chunks):
+            depth = np.stack([f.result() for f in reads])
+            reads = [pool.submit(read_depth, x) for x in chunks[n + 1]] if n + 1 < len(chunks) else []
+            dicts = [io_utils.get_params_from_syn_file(x) for x in chunk]
+            params = [[d["azimuth"], d["elevation"], d["tilt"], d["rho"]] for d in dicts]
+            crops = [d["crop_params"] for d in dicts]
+            flows = make_disparity_maps(key_3d, params, depth, crops, point_order=order)
+            writes += [pool.submit(np.save, os.path.join(save_dir, name.split(".")[0]), flow)
+                       for name, flow in zip(chunk, flows)]
+        for f in writes:
+            f.result()                               # re-raises what a writer thread hit
     return len(images)

@@ -322,10 +322,14 @@ def test_script_entry_points_on_a_data_tree(pea, tmp_path, golden_geometry):
             renders.append((name, d, depth))
         (tmp_path / "g_save_file_location_final" / "04256520_other_a0@000_e0@000_t0@000_d2@000_1_2_3_4_.jpg").write_bytes(b"")
         assert pea.make_disparity_syn.make_disparity("chair") == 3
+        one_batch = {name: np.load(tmp_path / "syn_disparity_loc" / (name.split(".")[0] + ".npy")) for name, _, _ in renders}
+        # again in batches of two: the next batch's depth files are read while the first is on the GPU
+        assert pea.make_disparity_syn.make_disparity("chair", batch=2) == 3
         assert pea.make_dense_pointset_syn.make_dense_keypoints("chair") == 3
         for name, d, depth in renders:
             params = [d["azimuth"], d["elevation"], d["tilt"], d["rho"]]
             flow = np.load(tmp_path / "syn_disparity_loc" / (name.split(".")[0] + ".npy"))
+            assert np.array_equal(flow, one_batch[name])
             assert flow.dtype == np.float64 and flow.shape == (224, 224, 2)
             assert np.array_equal(flow, odisp.make_disparity_core(pts, params, depth, d["crop_params"]))
             keys = np.load(tmp_path / "syn_dense_keypoint_loc" / (name.split(".")[0] + ".npy"))
