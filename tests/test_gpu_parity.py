@@ -636,7 +636,7 @@ def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
         assert np.array_equal(ind[i], want_i), f"pair {i}: {np.sum(ind[i] != want_i)} index mismatches"
         finite = np.isfinite(want_d)
         # squared distances: 1e-4 RELATIVE, no absolute floor (an exact match must come back as 0)
-        assert np.all(np.abs(dist[i] - want_d)[finite] <= 1e-4 * np.abs(want_d[finite]))
+        assert np.all(np.abs(dist[i][finite] - want_d[finite]) <= 1e-4 * np.abs(want_d[finite]))
         assert np.all(np.isinf(dist[i][~finite]))
     return st
 
