@@ -959,6 +959,21 @@ def test_nn_split_filter(pea):
     assert torch.equal(i0, i1)
 
 
+def test_nn_split_long_and_uneven_float64_queues(pea):
+    """Split filter with two pairs whose every query ties exactly among 128 copies of a reference (all 1024
+    queries of those pairs go through the batched float64 pass, more than one round of its workgroups per pair)
+    next to pairs with few or no queued queries: lowest index among the ties, other pairs untouched."""
+    rs = np.random.RandomState(97)
+    b, c, nq, nr = 40, 128, 1024, 1024
+    q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
+    for heavy in (3, 29):
+        base = _unit(rs, (1, c, 8))[0]
+        r[heavy] = np.tile(base, (1, nr // 8))
+        q[heavy] = base[:, rs.randint(0, 8, nq)]
+    st = _nn_check(pea, q, r, 1, split=True)
+    assert st["full_rescans"] >= 2 * nq
+
+
 def test_nn_pointers_off_the_16_byte_grid(pea):
     """Feature maps that start one or a few elements into an allocation (views into a larger
     buffer): the 16-byte loaders and LDS-direct paths must stand aside, results unchanged."""
