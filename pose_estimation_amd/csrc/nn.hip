@@ -394,9 +394,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     }
 
     // float64 pass: pairs with long queues (when queues are long on average) share one sweep over
-    // their reference map among kQB queries; everything else goes one query per block
-    // (only the split filter's wider bound makes queues long enough: the other paths skip the launch)
-    const bool batched = p.split && k == 1 && nr % 4 == 0 && (uintptr_t)r % 16 == 0 &&
+    // their reference map among kQB queries; everything else goes one query per block.  Queues get long
+    // behind the split filter (its bound is wider) and, with any filter, on maps with exactly tied cells
+    // (masked or padded regions: every query whose nearest cell is one of them has to be settled here);
+    // otherwise the launch finds nothing to do and ends at once.
+    const bool batched = k == 1 && !small && nr % 4 == 0 && (uintptr_t)r % 16 == 0 &&
                          (size_t)kQB * C * sizeof(double) <= 48 * 1024;
     if (batched) {
         int per_pair = (int)(2048 / B);

@@ -959,10 +959,11 @@ def test_nn_split_filter(pea):
     assert torch.equal(i0, i1)
 
 
-def test_nn_split_long_and_uneven_float64_queues(pea):
-    """Split filter with two pairs whose every query ties exactly among 128 copies of a reference (all 1024
-    queries of those pairs go through the batched float64 pass, more than one round of its workgroups per pair)
-    next to pairs with few or no queued queries: lowest index among the ties, other pairs untouched."""
+@pytest.mark.parametrize("mode", ["f32", "bf16", "split"])
+def test_nn_long_and_uneven_float64_queues(pea, mode):
+    """Two pairs whose every query ties exactly among 128 copies of a reference (all 1024 queries of those
+    pairs go through the batched float64 pass, more than one round of its workgroups per pair) next to pairs
+    with few or no queued queries: lowest index among the ties, other pairs untouched."""
     rs = np.random.RandomState(97)
     b, c, nq, nr = 40, 128, 1024, 1024
     q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
@@ -970,7 +971,7 @@ def test_nn_split_long_and_uneven_float64_queues(pea):
         base = _unit(rs, (1, c, 8))[0]
         r[heavy] = np.tile(base, (1, nr // 8))
         q[heavy] = base[:, rs.randint(0, 8, nq)]
-    st = _nn_check(pea, q, r, 1, split=True)
+    st = _nn_check(pea, q, r, 1, bf16=(mode == "bf16"), split=(mode == "split"))
     assert st["full_rescans"] >= 2 * nq
 
 
