@@ -261,10 +261,11 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
         }
     };
 
-    // one chunk in ring slot `slot`, a compile-time constant (the loop is unrolled over the two slots: LDS
-    // addresses are loop-invariant lane registers plus immediates, the staging's m0 values constants)
+    // one chunk in ring slot `slot`; up to 192 channels a compile-time constant (the loop is unrolled over the
+    // two slots: LDS addresses are loop-invariant lane registers plus immediates, the staging's m0 values
+    // constants), above that a loop variable (the body laid out three times sends the fragment arrays to scratch)
     auto chunk_body = [&](int chunk, auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
+        const int slot = slot_c;
         const char *img = ring + slot * kSlot;
         const float *nh = nhbuf + slot * kBR;
         const f32x4 init_a[2] = {load_init(nh, 0, 0), load_init(nh, 0, 1)};
@@ -279,12 +280,16 @@ __global__ __launch_bounds__(256, KS32 > 4 ? 1 : 2) void nn_filter_split_kernel(
         stage(clamp_chunk(chunk + 2), slot);
         if (wq_u == 0) fetch_nh(clamp_chunk(chunk + 2));
     };
-    int chunk = 0;
-    for (; chunk + 2 <= nchunks; chunk += 2) {
-        chunk_body(chunk, std::integral_constant<int, 0>{});
-        chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+    if constexpr (KS32 <= 6) {
+        int chunk = 0;
+        for (; chunk + 2 <= nchunks; chunk += 2) {
+            chunk_body(chunk, std::integral_constant<int, 0>{});
+            chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+        }
+        if (chunk < nchunks) chunk_body(chunk, std::integral_constant<int, 0>{});
+    } else {
+        for (int chunk = 0; chunk < nchunks; ++chunk) chunk_body(chunk, chunk & 1);
     }
-    if (chunk < nchunks) chunk_body(chunk, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {
 #pragma unroll

@@ -222,12 +222,14 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         init_a[0] = load_init(nhbuf, 0, 0);
         init_a[1] = load_init(nhbuf, 0, 1);
     }
-    // One chunk, in ring slot `slot` (a compile-time constant: the loop below is unrolled over the three slots,
-    // so every LDS address of the body is a loop-invariant lane register plus an immediate offset, and the
-    // staging's m0 values are constants - no per-chunk address arithmetic).
+    // One chunk, in ring slot `slot`.  Up to 192 channels the slot is a compile-time constant: the loop below is
+    // unrolled over the three slots, so every LDS address of the body is a loop-invariant lane register plus an
+    // immediate offset, and the staging's m0 values are constants - no per-chunk address arithmetic.  Above that
+    // the body is too long to be laid out five times (the compiler then indexes the fragment arrays through
+    // scratch memory, a hundred times slower) and the slot stays a loop variable.
     auto chunk_body = [&](int chunk, auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
-        constexpr int next_slot = (slot + 1) % 3, after_slot = (slot + 2) % 3;
+        const int slot = slot_c;
+        const int next_slot = (slot + 1) % 3, after_slot = (slot + 2) % 3;
         const char *rimg = rbuf + slot * kRBuf;
         const char *next_img = rbuf + next_slot * kRBuf;
         const f32x4 init_b[2] = {load_init(nhbuf + slot * kBR, 1, 0), load_init(nhbuf + slot * kBR, 1, 1)};
@@ -243,15 +245,23 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 1, next_img, 0, a, init_b, acc_b, acc_a, chunk, 0);
     };
-    int chunk = 0;
-    for (; chunk + 3 <= nchunks; chunk += 3) {
-        chunk_body(chunk, std::integral_constant<int, 0>{});
-        chunk_body(chunk + 1, std::integral_constant<int, 1>{});
-        chunk_body(chunk + 2, std::integral_constant<int, 2>{});
-    }
-    if (chunk < nchunks) {
-        chunk_body(chunk, std::integral_constant<int, 0>{});
-        if (chunk + 1 < nchunks) chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+    if constexpr (KS32 <= 6) {
+        int chunk = 0;
+        for (; chunk + 3 <= nchunks; chunk += 3) {
+            chunk_body(chunk, std::integral_constant<int, 0>{});
+            chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+            chunk_body(chunk + 2, std::integral_constant<int, 2>{});
+        }
+        if (chunk < nchunks) {
+            chunk_body(chunk, std::integral_constant<int, 0>{});
+            if (chunk + 1 < nchunks) chunk_body(chunk + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        int slot = 0;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            chunk_body(chunk, slot);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may still be landing in LDS at exit
     if (nchunks > 0) {                                   // second half of the last chunk

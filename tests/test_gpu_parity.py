@@ -975,6 +975,32 @@ def test_nn_long_and_uneven_float64_queues(pea, mode):
     assert st["full_rescans"] >= 2 * nq
 
 
+def test_nn_time_grows_with_channels_not_faster(pea):
+    """A timing guard with a wide margin: twice the channels must not cost more than five times the time (a
+    filter kernel whose register arrays land in scratch memory is a hundred times slower and still exact)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def ms_per_call(c, dtype, flt):
+        x = torch.randn(2, 16, c, 4096, device="cuda", generator=g)
+        x = (x / x.norm(dim=2, keepdim=True)).to(dtype).contiguous()
+        for _ in range(2):
+            pea.correspondence.dense_nn(x[0], x[1], 1, filter=flt)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(3):
+            pea.correspondence.dense_nn(x[0], x[1], 1, filter=flt)
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1) / 3
+
+    for dtype, flt in ((torch.bfloat16, "native"), (torch.float32, "split"), (torch.float32, "native")):
+        base = ms_per_call(128, dtype, flt)
+        for c in (192, 224, 256):
+            t = ms_per_call(c, dtype, flt)
+            assert t < 5.0 * base * c / 128 + 0.2, (str(dtype), flt, c, t, base)
+
+
 def test_nn_pointers_off_the_16_byte_grid(pea):
     """Feature maps that start one or a few elements into an allocation (views into a larger
     buffer): the 16-byte loaders and LDS-direct paths must stand aside, results unchanged."""
