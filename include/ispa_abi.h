@@ -42,8 +42,9 @@ typedef enum ispa_status {
 } ispa_status;
 
 enum { ISPA_VIS_A = 0, ISPA_VIS_B = 1 };          /* depth-visibility variants         */
-/* feature dtypes for ispa_nn_topk; ISPA_F32_SPLIT = float32 inputs, split-bfloat16 MFMA filter */
-enum { ISPA_F32 = 0, ISPA_BF16 = 1, ISPA_F32_SPLIT = 2 };
+/* feature dtypes for ispa_nn_topk; ISPA_F32_SPLIT = float32 inputs, split-bfloat16 MFMA filter where it is
+ * the faster one; ISPA_F32_SPLIT_ALWAYS = the same, also for calls too small for it to pay (tests, timing) */
+enum { ISPA_F32 = 0, ISPA_BF16 = 1, ISPA_F32_SPLIT = 2, ISPA_F32_SPLIT_ALWAYS = 3 };
 /* OR'ed into the dtype of ispa_nn_topk (float32 features only): L2NormLayer.forward
  * (ucn_code/lib/layers/l2norm_layer.py:18-29) is applied to both maps inside the norms pass, i.e. the call
  * returns what ispa_l2norm on q and r followed by ispa_nn_topk returns, bit for bit; the normalised copies
@@ -214,8 +215,9 @@ int ispa_zbuffer_tiled(const double *pt_render, int64_t n, int n_pose, int H, in
  * references that the filter could not separate.
  * ISPA_F32_SPLIT takes the same float32 arrays as ISPA_F32 and returns the same exact index order;
  * its filter pass runs the contraction on bfloat16 MFMAs over a hi/lo split of the inputs (top-1,
- * C a multiple of 32 up to 256, cell counts multiples of 8; other requests run as ISPA_F32) and
- * needs a larger workspace: ask ispa_nn_workspace_bytes_for. */
+ * C a multiple of 32 up to 256, cell counts multiples of 8; other requests, and calls of less than
+ * 1e11 floating-point operations (2 B nq nr C), which the float32 filter finishes sooner, run as
+ * ISPA_F32) and needs a larger workspace: ask ispa_nn_workspace_bytes_for. */
 size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);     /* ISPA_F32 / ISPA_BF16 */
 size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k);
 int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,

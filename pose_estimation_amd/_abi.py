@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("ISPA_HIP_LIBRARY") or os.path.join(_HERE, "libispa_hi
 
 ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1
-F32, BF16, F32_SPLIT = 0, 1, 2
+F32, BF16, F32_SPLIT, F32_SPLIT_ALWAYS = 0, 1, 2, 3
 NN_NORMALIZE = 256
 PCK_MAX_RADII = 8
 PRUNE_POLYGON, PRUNE_BAND, PRUNE_DROP = 1, 2, 4

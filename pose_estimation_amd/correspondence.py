@@ -37,7 +37,9 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     exact with respect to float64 arithmetic on the given inputs.
 
     filter="split" (float32 inputs, k=1): the filter pass contracts a bfloat16 hi/lo split of the
-    inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones.
+    inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones.  Calls too small
+    for that to pay (under 1e11 operations) run the float32 filter; filter="split-always" keeps the split
+    filter for them too (tests, timing).
 
     normalize=True (float32 inputs): both maps pass through L2NormLayer.forward (l2norm_layer.py:18-29)
     inside the call, as the reference's net does in front of the KNN layer (train.prototxt:2096-2115); the
@@ -46,8 +48,8 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     num_query (B,) or (B,1): the layer's `num_coord` bottom with `use_all_query: false`
     (train.prototxt:2128-2141) - only the first num_query[b] query columns of item b are real; the
     others come back as index -1 and distance +inf."""
-    if filter not in ("native", "split"):
-        raise ValueError("filter must be 'native' or 'split'")
+    if filter not in ("native", "split", "split-always"):
+        raise ValueError("filter must be 'native', 'split' or 'split-always'")
     as_tensor = dv.is_tensor(query)
     bf16 = as_tensor and query.dtype == torch.bfloat16
     tdt = torch.bfloat16 if bf16 else torch.float32
@@ -64,7 +66,7 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     dist = dv.empty((b, k, nq), torch.float32)
     ind = dv.empty((b, k, nq), torch.int32)
     stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
-    code = _abi.BF16 if bf16 else (_abi.F32_SPLIT if filter == "split" else _abi.F32)
+    code = _abi.BF16 if bf16 else {"native": _abi.F32, "split": _abi.F32_SPLIT, "split-always": _abi.F32_SPLIT_ALWAYS}[filter]
     if normalize:
         if bf16:
             raise ValueError("normalize=True takes float32 features")

@@ -443,10 +443,12 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
 extern "C" size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
-    const int base = dtype & ~ISPA_NN_NORMALIZE, flag = dtype & ISPA_NN_NORMALIZE;
+    int base = dtype & ~ISPA_NN_NORMALIZE;
+    const int flag = dtype & ISPA_NN_NORMALIZE;
+    if (base == ISPA_F32_SPLIT_ALWAYS) base = ISPA_F32_SPLIT;
     if (base != ISPA_F32 && base != ISPA_BF16 && base != ISPA_F32_SPLIT) return 0;
     if (flag && base == ISPA_BF16) return 0;
-    const size_t a = make_plan(dtype, B, C, nq, nr, k).total;
+    const size_t a = make_plan(base | flag, B, C, nq, nr, k).total;
     const size_t b = make_plan(ISPA_F32 | flag, B, C, nq, nr, k).total;   // the plan a call may fall back to
     return a > b ? a : b;
 }
@@ -526,6 +528,8 @@ int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64
     ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
     const int flags = dtype & ISPA_NN_NORMALIZE;
     dtype &= ~ISPA_NN_NORMALIZE;
+    const bool split_always = dtype == ISPA_F32_SPLIT_ALWAYS;
+    if (split_always) dtype = ISPA_F32_SPLIT;
     ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16 || dtype == ISPA_F32_SPLIT, "unknown dtype %d", dtype);
     ISPA_REQUIRE(!(flags && dtype == ISPA_BF16), "ISPA_NN_NORMALIZE takes float32 features");
     Plan p = make_plan(dtype | flags, B, C, nq, nr, k);
@@ -534,6 +538,13 @@ int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64
         p.bf16_mfma = false;
         p.t16 = false;
         p.split = false;
+    }
+    // The split filter pays for itself from about 100 GFLOP per call (its extra passes - hi / lo images, wider
+    // margins, more float64 work - are nine launches); smaller calls get the same results sooner from the
+    // float32 filter and its few-launch path for small problems.
+    if (p.split && !split_always && 2.0 * B * (double)nq * (double)nr * C < 1.0e11) {
+        dtype = ISPA_F32;
+        p = make_plan(ISPA_F32 | flags, B, C, nq, nr, k);
     }
     if (workspace_bytes < p.total)
         return ispa::fail(ISPA_EWORKSPACE, "%s of %zu bytes given, %zu needed", workspace_name, workspace_bytes, p.total);

@@ -10,6 +10,16 @@ __device__ __forceinline__ bool key_less(double d0, int j0, double d1, int j1) {
     return d0 < d1 || (d0 == d1 && j0 < j1);
 }
 
+// Which of the two kernels below takes a queued query.  nn_exact_top1_kernel lets the queued queries of a pair
+// share sweeps over the pair's reference map, which saves reads, not latency: it takes the pairs with at least
+// `batch_min` queued queries, and only when queues are that long on average and the whole queue is long enough
+// to fill the chip several times one query per workgroup (a few long shared sweeps on an otherwise idle chip
+// take longer than many short ones side by side).  Both kernels evaluate this same predicate.
+constexpr int kBatchTotalMin = 2048;
+__device__ __forceinline__ bool batched_pass_runs(int total, int batch_min, int n_pair) {
+    return total >= (int64_t)batch_min * n_pair && total >= kBatchTotalMin;
+}
+
 // One block (NT threads: 1024 for long reference maps, where a single queued query would otherwise set the
 // duration of the launch) per queued query.  d2(j) = (qq + rr_j) - 2 dot_j with dot accumulated over channels in
 // increasing order in float64 (every product of two float32 values is exact in float64); qq and
@@ -30,9 +40,8 @@ __global__ __launch_bounds__(NT) void nn_exact_kernel(const T *__restrict__ q, c
     int *sj = reinterpret_cast<int *>(sd + NT);                    // NT ints
     int *sown = sj + NT;                                           // NT ints
     const int count = *amb_count;
-    // pairs with long queues belong to nn_exact_top1_kernel, but only when queues are long on
-    // average: sharing reference reads pays off in bandwidth, not in latency
-    const bool some_batched = count >= (int64_t)skip_from * n_pair;
+    // pairs with long queues belong to nn_exact_top1_kernel (skip_from is out of reach when it does not run)
+    const bool some_batched = batched_pass_runs(count, skip_from, n_pair);
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int64_t flat = amb_list[w];
         const int b = (int)(flat / nq);
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256) void nn_exact_top1_kernel(const T *__restrict_
     // with the batch slot fastest the busy ones (a pair's first slots) would land on every second XCD only.
     const int b = blockIdx.x;
     const int count = pair_count[b];
-    if (count < kBatchMin || *total_count < kBatchMin * (int)gridDim.x) return;
+    if (count < kBatchMin || !batched_pass_runs(*total_count, kBatchMin, (int)gridDim.x)) return;
     const T *rb = r + (int64_t)b * C * nr;
     const double *rrb = rr64 + (int64_t)b * nr;
     for (int base = blockIdx.y * kQB; base < count; base += gridDim.y * kQB) {

@@ -621,7 +621,7 @@ def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
     import torch
     b = q.shape[0]
     if split:
-        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, filter="split")
+        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, filter="split-always")
     elif bf16:
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
@@ -930,6 +930,11 @@ def test_nn_split_filter(pea):
     # 160 .. 256 channels: one block per CU
     for c in (160, 192, 224, 256):
         _nn_check(pea, _unit(rs, (1, c, 264)), _unit(rs, (1, c, 1032)), 1, split=True)
+    # filter="split" on a call too small for the split filter to pay: routed to the float32 filter, same results
+    qs, rs_ = _unit(rs, (2, 128, 512)), _unit(rs, (2, 128, 1024))
+    d_auto, i_auto = pea.correspondence.dense_nn(qs, rs_, 1, filter="split")
+    d_nat, i_nat = pea.correspondence.dense_nn(qs, rs_, 1)
+    assert np.array_equal(i_auto, i_nat) and np.array_equal(d_auto, d_nat)
     # requests the split kernel does not take run as plain float32 (k > 1, odd sizes, C = 288)
     _nn_check(pea, _unit(rs, (1, 128, 256)), _unit(rs, (1, 128, 512)), 5, split=True)
     _nn_check(pea, _unit(rs, (2, 48, 100)), _unit(rs, (2, 48, 333)), 1, split=True)
@@ -952,10 +957,10 @@ def test_nn_split_filter(pea):
     rr = rr / rr.norm(dim=1, keepdim=True)
     perm = torch.stack([torch.randperm(4096, device="cuda", generator=g) for _ in range(16)])
     qq = torch.gather(rr, 2, perm[:, None, :].expand(-1, 128, -1)).contiguous()
-    d, i = pea.correspondence.dense_nn(qq, rr, 1, index_base=0, filter="split")
+    d, i = pea.correspondence.dense_nn(qq, rr, 1, index_base=0, filter="split-always")
     assert torch.equal(i[:, 0, :].long(), perm) and float(d.abs().max()) == 0.0
     d0, i0 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0)
-    d1, i1 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0, filter="split")
+    d1, i1 = pea.correspondence.dense_nn(qq, rr.roll(1, 2).contiguous(), 1, index_base=0, filter="split-always")
     assert torch.equal(i0, i1)
 
 
@@ -994,7 +999,7 @@ def test_nn_time_grows_with_channels_not_faster(pea):
         torch.cuda.synchronize()
         return t0.elapsed_time(t1) / 3
 
-    for dtype, flt in ((torch.bfloat16, "native"), (torch.float32, "split"), (torch.float32, "native")):
+    for dtype, flt in ((torch.bfloat16, "native"), (torch.float32, "split-always"), (torch.float32, "native")):
         base = ms_per_call(128, dtype, flt)
         for c in (192, 224, 256):
             t = ms_per_call(c, dtype, flt)
@@ -1019,7 +1024,7 @@ def test_nn_pointers_off_the_16_byte_grid(pea):
                 qd.copy_(torch.from_numpy(q))
                 rd.copy_(torch.from_numpy(r))
                 assert qd.data_ptr() % 16 != 0 and rd.data_ptr() % 16 != 0
-                d, i = pea.correspondence.dense_nn(qd, rd, k, 1, filter="split" if mode == "split" else "native")
+                d, i = pea.correspondence.dense_nn(qd, rd, k, 1, filter="split-always" if mode == "split" else "native")
                 qo = cnative.round_bf16(q) if mode == "bf16" else q
                 ro = cnative.round_bf16(r) if mode == "bf16" else r
                 for p in range(b):

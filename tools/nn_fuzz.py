@@ -21,7 +21,7 @@ def check(q, r, k, mode, index_base):
         dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
         q, r = cnative.round_bf16(q), cnative.round_bf16(r)
     else:
-        dist, ind = pea.correspondence.dense_nn(q, r, k, index_base, filter="split" if mode == "split" else "native")
+        dist, ind = pea.correspondence.dense_nn(q, r, k, index_base, filter="split-always" if mode == "split" else "native")
     for i in range(q.shape[0]):
         want_i, want_d = cnative.nn_exact(q[i], r[i], k, index_base)
         if not np.array_equal(ind[i], want_i):
