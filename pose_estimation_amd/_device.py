@@ -34,6 +34,14 @@ def to_dev(x, dtype):
     return t.contiguous()
 
 
+def rows(x, cols, dtype):
+    """Small parameter table (crop boxes, ...) given as list, numpy array or tensor on any device -> contiguous
+    (n, cols) device tensor of `dtype`."""
+    if is_tensor(x):
+        return to_dev(x.reshape(-1, cols), dtype)
+    return to_dev(np.asarray(x).reshape(-1, cols), dtype)
+
+
 def empty(shape, dtype):
     return torch.empty(shape, dtype=dtype, device=device())
 

@@ -104,7 +104,7 @@ def dense_keypoints_for_renders(anchors, class_name, params, depth_maps, crop_pa
     depth = np.asarray(depth_maps)
     if depth.ndim == 2:
         depth = depth[None]
-    truth, key_2d = run_proj.project_prune(pts3d, cams, depth, np.asarray(crop_params).reshape(len(params), 4))
+    truth, key_2d = run_proj.project_prune(pts3d, cams, depth, crop_params)
     key_2d = key_2d[:, :2, :].copy()
     key_2d[~np.broadcast_to(truth[:, None, :], key_2d.shape)] = 0
     return key_2d

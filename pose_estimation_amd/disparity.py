@@ -95,14 +95,16 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
     depth = dv.to_dev(depth_maps, torch.float32)
     if depth.dim() == 2:
         depth = depth[None]
-    crops = np.asarray(crop_params).reshape(n_map, 4)
+    crops = dv.rows(crop_params, 4, torch.int32)
+    if crops.shape[0] != n_map:
+        raise ValueError("need one crop box per render")
     if fused:
         h, w = depth.shape[-2:]
         if depth.shape[0] not in (1, n_map):
             raise ValueError("need one depth map per render or a single shared one")
         c1 = dv.to_dev(cams1, torch.float64)
         c2 = dv.to_dev(cams2, torch.float64)
-        crop_t = dv.to_dev(crops, torch.int32)
+        crop_t = crops
         flow = dv.empty((n_map, FLOW_SIDE, FLOW_SIDE, 2), torch.float64)
         # one word of workspace per (render, point): the per-point work then runs once, not once per band
         need = _abi.lib.ispa_make_disparity_workspace_bytes(pts.shape[0], n_map)

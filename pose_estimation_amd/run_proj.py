@@ -140,7 +140,7 @@ def project_prune(model_pts, cams, depth_maps, crop_params=None, variant="A", er
         raise ValueError("need one depth map per pose or a single shared one")
     crop_t, crop_per_pose = None, 0
     if crop_params is not None:
-        crop_t = dv.to_dev(np.asarray(crop_params).reshape(-1, 4), torch.int32)
+        crop_t = dv.rows(crop_params, 4, torch.int32)
         crop_per_pose = 1 if crop_t.shape[0] > 1 else 0
         if crop_per_pose and crop_t.shape[0] != n_pose:
             raise ValueError("need one crop per pose or a single shared one")

@@ -293,6 +293,23 @@ def test_make_disparity_ordered_100k_and_bad_ranks(pea):
     assert rc == -1
 
 
+def test_crop_tables_may_be_device_tensors(pea):
+    """Crop boxes as a list, a numpy array or a tensor already on the GPU give the same results."""
+    import torch
+    rs = np.random.RandomState(12)
+    pts = rs.uniform(-0.35, 0.35, (5000, 3))
+    params = np.array([[30.0, 10.0, 0.0, 3.0], [200.0, -5.0, 3.0, 2.5]])
+    cams = np.stack([pea.run_proj.camera_from_params(p) for p in params])
+    depth = np.full((540, 960), 3.0, dtype=np.float32)
+    crops = [[60, 470, 250, 720], [40, 500, 200, 760]]
+    t0, p0 = pea.run_proj.project_prune(pts, cams, depth, crops)
+    t1, p1 = pea.run_proj.project_prune(pts, cams, depth, torch.tensor(crops, dtype=torch.int64, device="cuda"))
+    assert np.array_equal(t0, t1) and np.array_equal(p0, p1)
+    f0 = pea.disparity.make_disparity_maps(pts, params, depth, np.asarray(crops))
+    f1 = pea.disparity.make_disparity_maps(pts, params, depth, torch.tensor(crops, device="cuda"))
+    assert np.array_equal(f0, f1)
+
+
 def test_script_entry_points_on_a_data_tree(pea, tmp_path, golden_geometry):
     """make_disparity / make_dense_keypoints over a directory laid out like the reference's ../data."""
     gv = pea.global_variables
