@@ -100,7 +100,7 @@ def dense_keypoints_for_renders(anchors, class_name, params, depth_maps, crop_pa
     coords = get_additional_coords_keypoint_5(np.asarray(anchors, dtype=np.float64).T, class_name)
     pts3d = np.ascontiguousarray(dense_skeleton(coords, class_name).T)
     params = np.atleast_2d(np.asarray(params, dtype=np.float64))
-    cams = np.stack([run_proj.camera_from_params(p) for p in params])
+    cams = run_proj.cameras_from_params(params)
     depth = np.asarray(depth_maps)
     if depth.ndim == 2:
         depth = depth[None]

@@ -86,11 +86,11 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
         raise ValueError("point_order goes with the fused path and must describe key_3d")
     params = np.atleast_2d(np.asarray(params, dtype=np.float64))
     n_map = params.shape[0]
-    cams1 = np.stack([run_proj.camera_from_params(p) for p in params])
+    cams1 = run_proj.cameras_from_params(params)
     more = params.copy()
     more[:, 0] += POSE_STEP[0]
     more[:, 1] += POSE_STEP[1]
-    cams2 = np.stack([run_proj.camera_from_params(p) for p in more])
+    cams2 = run_proj.cameras_from_params(more)
     pts = dv.to_dev(key_3d, torch.float64)
     depth = dv.to_dev(depth_maps, torch.float32)
     if depth.dim() == 2:
@@ -141,8 +141,8 @@ def demo_flow(key_3d, params, depth_maps, step=DEMO_STEP, spread=SPREAD):
     more = params.copy()
     more[:, 0] += step[0]
     more[:, 1] += step[1]
-    cams1 = np.stack([run_proj.camera_from_params(p) for p in params])
-    cams2 = np.stack([run_proj.camera_from_params(p) for p in more])
+    cams1 = run_proj.cameras_from_params(params)
+    cams2 = run_proj.cameras_from_params(more)
     pts = dv.to_dev(key_3d, torch.float64)
     depth = dv.to_dev(depth_maps, torch.float32)
     if depth.dim() == 3 and depth.shape[0] == 1:

@@ -15,6 +15,29 @@ def camera_from_params(params):
     return pt2render.get_camera_matrix(variables.INTRINSIC_CAMERA_MATRIX, ext, variables.WORLD_MATRIX)
 
 
+_batched_cameras_exact = None
+
+
+def cameras_from_params(params):
+    """camera_from_params of every row of params (n,4) -> (n,3,4), bit for bit.
+
+    pt2render.camera_matrices computes all rows at once (under 1 us per pose instead of 36); whether numpy's
+    array routines round like its per-matrix ones is a property of the numpy build, so the first call compares
+    the two on a fixed set of poses and the per-pose loop is kept if a single bit differs."""
+    global _batched_cameras_exact
+    params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    if _batched_cameras_exact is None:
+        rs = np.random.RandomState(7)
+        probe = np.stack([rs.uniform(0, 360, 64), rs.uniform(-30, 60, 64), rs.uniform(-15, 15, 64),
+                          rs.uniform(1.5, 4, 64)], 1)
+        probe[:16, :3] = np.round(probe[:16, :3])
+        _batched_cameras_exact = np.array_equal(pt2render.camera_matrices(probe),
+                                                np.stack([camera_from_params(p) for p in probe]))
+    if _batched_cameras_exact:
+        return pt2render.camera_matrices(params)
+    return np.stack([camera_from_params(p) for p in params])
+
+
 def load_obj(file_name):
     """Vertices (V,3) float64 and triangles (F,3) int64 of a Wavefront .obj (polygons are fanned; negative
     indices count from the end, as the format allows)."""

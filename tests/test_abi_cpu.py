@@ -135,3 +135,15 @@ def test_one_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[0] == "1", out.stdout
+
+
+def test_cameras_from_params_matches_the_per_pose_functions_bit_for_bit():
+    import numpy as np
+    from pose_estimation_amd import run_proj
+    rs = np.random.RandomState(21)
+    poses = np.stack([rs.uniform(0, 360, 2000), rs.uniform(-30, 60, 2000), rs.uniform(-15, 15, 2000),
+                      rs.uniform(1.5, 4, 2000)], 1)
+    poses[:200, :3] = np.round(poses[:200, :3])
+    want = np.stack([run_proj.camera_from_params(p) for p in poses])
+    assert np.array_equal(run_proj.cameras_from_params(poses), want)
+    assert run_proj.cameras_from_params(poses[0]).shape == (1, 3, 4)
