@@ -22,8 +22,7 @@ def make_dense_keypoints(class_name, batch=256):
         dicts = [io_utils.get_params_from_syn_file(x) for x in chunk]
         params = [[d["azimuth"], d["elevation"], d["tilt"], d["rho"]] for d in dicts]
         crops = [d["crop_params"] for d in dicts]
-        depth = np.stack([run_proj.get_depthmap_from_exr(os.path.join(gv.depth_loc, io_utils.img_to_depth_file(x)))
-                          for x in chunk])
+        depth = run_proj.load_depth_stack(os.path.join(gv.depth_loc, io_utils.img_to_depth_file(x)) for x in chunk)
         keys = dense_pointset.dense_keypoints_for_renders(anchors, class_name, params, depth, crops)
         for name, key_2d in zip(chunk, keys):
             np.save(os.path.join(save_loc, name.split(".")[0]), key_2d)

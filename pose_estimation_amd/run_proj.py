@@ -124,6 +124,17 @@ def get_depthmap_from_exr(file_name):
         raise
 
 
+def load_depth_stack(file_names, threads=8):
+    """get_depthmap_from_exr of every file -> (n,H,W) float32, decoded on `threads` host threads (the inflate
+    calls that dominate a decode run outside the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
+    file_names = list(file_names)
+    if threads <= 1 or len(file_names) <= 1:
+        return np.stack([get_depthmap_from_exr(f) for f in file_names])
+    with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+        return np.stack(list(pool.map(get_depthmap_from_exr, file_names)))
+
+
 def _depth_array(depth):
     return get_depthmap_from_exr(depth) if isinstance(depth, str) else depth
 
