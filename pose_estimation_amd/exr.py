@@ -60,12 +60,12 @@ def _channels(raw):
 
 def _undo_predictor(data):
     """Inverse of the ZIP / RLE byte predictor and of the even / odd byte split."""
-    t = np.frombuffer(data, dtype=np.uint8).astype(np.int64)
+    t = np.frombuffer(data, dtype=np.uint8).copy()
     if t.size:
-        # t[i] = t[i-1] + d[i] - 128 (mod 256)  ==  cumulative sum of (d[i] - 128) on top of d[0]
-        t[1:] -= 128
-        t = np.cumsum(t) & 0xFF
-    t = t.astype(np.uint8)
+        # t[i] = t[i-1] + d[i] - 128 (mod 256)  ==  cumulative sum of (d[i] - 128) on top of d[0]; unsigned
+        # 8-bit arithmetic wraps modulo 256 by itself
+        t[1:] += 128                                   # -128 == +128 (mod 256)
+        t = np.cumsum(t, dtype=np.uint8)
     half = (t.size + 1) // 2
     out = np.empty(t.size, dtype=np.uint8)
     out[0::2] = t[:half]
