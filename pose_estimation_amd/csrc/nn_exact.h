@@ -12,10 +12,10 @@ __device__ __forceinline__ bool key_less(double d0, int j0, double d1, int j1) {
 
 // Which of the two kernels below takes a queued query.  nn_exact_top1_kernel lets the queued queries of a pair
 // share sweeps over the pair's reference map, which saves reads, not latency: it takes the pairs with at least
-// `batch_min` queued queries, and only when queues are that long on average and the whole queue is long enough
-// to fill the chip several times one query per workgroup (a few long shared sweeps on an otherwise idle chip
-// take longer than many short ones side by side).  Both kernels evaluate this same predicate.
-constexpr int kBatchTotalMin = 2048;
+// `batch_min` queued queries, and only when queues are that long on average and the whole queue gives at least
+// four dozen shared sweeps (a handful of long shared sweeps on an otherwise idle chip take longer than many short
+// ones side by side: one 128x128 pair queues 140 queries, 18 sweeps).  Both kernels evaluate this same predicate.
+constexpr int kBatchTotalMin = 384;
 __device__ __forceinline__ bool batched_pass_runs(int total, int batch_min, int n_pair) {
     return total >= (int64_t)batch_min * n_pair && total >= kBatchTotalMin;
 }
