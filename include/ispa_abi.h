@@ -216,7 +216,7 @@ int ispa_zbuffer_tiled(const double *pt_render, int64_t n, int n_pose, int H, in
  * ISPA_F32_SPLIT takes the same float32 arrays as ISPA_F32 and returns the same exact index order;
  * its filter pass runs the contraction on bfloat16 MFMAs over a hi/lo split of the inputs (top-1,
  * C a multiple of 32 up to 256, cell counts multiples of 8; other requests, and calls of less than
- * 1e11 floating-point operations (2 B nq nr C), which the float32 filter finishes sooner, run as
+ * 65536 queries (B nq), which the float32 filter finishes sooner, run as
  * ISPA_F32) and needs a larger workspace: ask ispa_nn_workspace_bytes_for. */
 size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k);     /* ISPA_F32 / ISPA_BF16 */
 size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k);

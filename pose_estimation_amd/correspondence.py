@@ -38,7 +38,7 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
 
     filter="split" (float32 inputs, k=1): the filter pass contracts a bfloat16 hi/lo split of the
     inputs on bfloat16 MFMAs instead of float32 MFMAs; results are the same exact ones.  Calls too small
-    for that to pay (under 1e11 operations) run the float32 filter; filter="split-always" keeps the split
+    for that to pay (under 65536 queries) run the float32 filter; filter="split-always" keeps the split
     filter for them too (tests, timing).
 
     normalize=True (float32 inputs): both maps pass through L2NormLayer.forward (l2norm_layer.py:18-29)

@@ -539,10 +539,11 @@ int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64
         p.t16 = false;
         p.split = false;
     }
-    // The split filter pays for itself from about 100 GFLOP per call (its extra passes - hi / lo images, wider
-    // margins, more float64 work - are nine launches); smaller calls get the same results sooner from the
-    // float32 filter and its few-launch path for small problems.
-    if (p.split && !split_always && 2.0 * B * (double)nq * (double)nr * C < 1.0e11) {
+    // The split filter pays for itself from about 65536 queries per call: its wider margins queue about 1 % of
+    // the queries for the float64 pass, and a short queue of long sweeps (one 128x128 pair: 140 of them) costs
+    // more than the filter saves; its extra passes (hi / lo images) are nine launches.  Smaller calls get the
+    // same results sooner from the float32 filter and its few-launch path for small problems.
+    if (p.split && !split_always && (int64_t)B * nq < 65536) {
         dtype = ISPA_F32;
         p = make_plan(ISPA_F32 | flags, B, C, nq, nr, k);
     }

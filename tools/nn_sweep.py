@@ -17,8 +17,8 @@ for c in (32, 64, 96, 128, 160, 192, 224, 256, 288, 100):
     x = x / x.norm(dim=2, keepdim=True)
     for k in (1, 5, 8):
         cells = []
-        for dtype, flt in ((torch.float32, "native"), (torch.bfloat16, "native"), (torch.float32, "split-always")):
-            if flt == "split-always" and k != 1:
+        for dtype, flt in ((torch.float32, "native"), (torch.bfloat16, "native"), (torch.float32, "split")):
+            if flt == "split" and k != 1:
                 cells.append("-")
                 continue
             q, r = x[0].to(dtype).contiguous(), x[1].to(dtype).contiguous()

@@ -17,8 +17,8 @@ for grid, b in ((28, 512), (56, 128), (56, 8), (60, 64), (64, 64), (96, 32), (12
     x = x / x.norm(dim=2, keepdim=True)
     for k in (1, 5):
         cells = []
-        for dtype, flt in ((torch.float32, "native"), (torch.bfloat16, "native"), (torch.float32, "split-always")):
-            if flt == "split-always" and k != 1:
+        for dtype, flt in ((torch.float32, "native"), (torch.bfloat16, "native"), (torch.float32, "split")):
+            if flt == "split" and k != 1:
                 cells.append("-")
                 continue
             q, r = x[0].to(dtype).contiguous(), x[1].to(dtype).contiguous()
