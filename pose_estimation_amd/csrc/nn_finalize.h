@@ -39,11 +39,12 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
     }
     // the lists of several streams are loaded together (a thread that waited for each entry before
     // asking for the next would spend ~1 us per entry: with many streams that is the kernel's duration)
-    constexpr int PB = K == 1 ? 8 : (K <= 5 ? 2 : 1);
+    constexpr int PB = K <= 5 ? 8 : 4;
     for (int p0 = 0; p0 < nparts; p0 += PB) {
         float xs[PB][K + 1];
         int cs[PB][K + 1];
-#pragma unroll
+        __builtin_amdgcn_sched_barrier(0);              // all loads of the batch first, then their uses: left
+#pragma unroll                                          // alone the compiler sinks each load to its use
         for (int e = 0; e < PB; ++e)
 #pragma unroll
             for (int s = 0; s <= K; ++s) {
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const float *__restric
                 xs[e][s] = part_val[o];
                 cs[e][s] = part_idx[o];
             }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < PB; ++e) {
             if (p0 + e >= nparts) break;
