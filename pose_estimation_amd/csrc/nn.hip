@@ -73,19 +73,26 @@ Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k)
     const int64_t want = 1024;
     int64_t nsplit = 1;
     const int64_t base = (int64_t)B * p.n_qtiles;
-    // The LDS-staged float32 filter (four workgroups per CU) keeps the plain rule: about `want` workgroups.
+    // The LDS-staged float32 filter (four workgroups per CU) keeps the plain rule on large calls: about `want`
+    // workgroups; small calls weigh the merge cost of the finalize pass like the other filters.
     const bool staged = !p.bf16_mfma && !p.split && !(p.ktemplate == 1 && C % 32 == 0 && C <= 128);
-    if (!staged) {
+    if (!staged || (int64_t)B * nq <= 524288) {
         // The other filters hold two workgroups per CU up to 128 channels and one above, and every
         // split stream pays a fixed price again: its query fragments and, for top-k, a sorted insert
         // for nearly every score of its first few hundred (measured: what ~800 further references
         // would cost; ~256 for top-1).  So: rounds of workgroups over the chip x (references per
         // split + that price), smallest wins.
-        const int64_t slots = 256 * (C > 128 ? 1 : 2);
+        // A split also gives the finalize pass `substreams` more lists to merge per query, one thread per query:
+        // on calls too small to fill the chip with those threads that chain of loads is what the pass lasts
+        // (measured on one 64x64 pair, top-5, 32 splits: 108 us for 128 lists, about what 32 further references
+        // per list cost the filter; 6 for the two-entry lists of top-1).
+        const int64_t slots = staged ? 1024 : 256 * (C > 128 ? 1 : 2);
         const int64_t warm = p.ktemplate > 1 ? 800 : 256;
+        const int64_t merge = (int64_t)B * nq <= 524288 ? substreams * (p.ktemplate > 1 ? 32 : 6) : 0;
         int64_t best_cost = -1;
         for (int64_t n = 1; n == 1 || chunks / n >= 2; n *= 2) {
-            const int64_t cost = ((base * n + slots - 1) / slots) * ((chunks + n - 1) / n * chunk_refs + warm);
+            const int64_t cost =
+                ((base * n + slots - 1) / slots) * ((chunks + n - 1) / n * chunk_refs + warm) + n * merge;
             if (best_cost < 0 || cost < best_cost) {
                 best_cost = cost;
                 nsplit = n;
