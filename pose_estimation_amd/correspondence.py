@@ -63,6 +63,14 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     nq, nr = q.shape[2], r.shape[2]
     if not 1 <= k <= 8:
         raise ValueError("k must be in [1, 8]")
+    # The fast filter kernels take cell counts that are multiples of 8 (16-byte rows).  A query count that is not
+    # (n sampled correspondences, as the KNN layer gets them) is brought there by repeating the last query column:
+    # queries are independent, the copies' results are dropped, and the call is about twice as fast as through
+    # the guarded loaders.  (Reference columns cannot be padded: a made-up cell could win.)
+    n_real = nq
+    if nq % 8 and nr % 8 == 0 and c % 32 == 0 and nq >= 8:
+        q = torch.cat([q, q[:, :, -1:].expand(b, c, 8 - nq % 8)], dim=2).contiguous()
+        nq = q.shape[2]
     dist = dv.empty((b, k, nq), torch.float32)
     ind = dv.empty((b, k, nq), torch.int32)
     stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
@@ -79,6 +87,9 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), code, b, c, nq, nr, k,
                                      int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
                                      dv.ptr(stats), dv.stream_ptr()))
+    if n_real != nq:
+        dist, ind = dist[:, :, :n_real].contiguous(), ind[:, :, :n_real].contiguous()
+        nq = n_real
     if num_query is not None:
         nv = dv.to_dev(np.asarray(num_query).reshape(-1) if not dv.is_tensor(num_query) else num_query.reshape(-1),
                        torch.int64)

@@ -1023,6 +1023,23 @@ def test_nn_time_grows_with_channels_not_faster(pea):
             assert t < 5.0 * base * c / 128 + 0.2, (str(dtype), flt, c, t, base)
 
 
+def test_nn_query_counts_off_the_8_cell_grid(pea):
+    """Query counts that are not multiples of 8 against an aligned reference map (n sampled correspondences, as
+    the KNN layer gets them): the host layer repeats the last query column up to the next multiple of 8 and drops
+    the copies; results and shapes are those of the given queries."""
+    rs = np.random.RandomState(31)
+    for (b, c, nq, nr, k, mode) in ((3, 128, 999, 1024, 1, "f32"), (2, 128, 1001, 1024, 1, "bf16"),
+                                    (2, 64, 77, 520, 5, "bf16"), (1, 128, 13, 784, 8, "f32"), (2, 128, 9, 1024, 1, "split")):
+        q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
+        _nn_check(pea, q, r, k, bf16=(mode == "bf16"), split=(mode == "split"))
+    # with the layer's query counts on top
+    q, r = _unit(rs, (2, 128, 203)), _unit(rs, (2, 128, 1024))
+    d, i = pea.correspondence.dense_nn(q, r, 1, num_query=[203, 57])
+    d0, i0 = pea.correspondence.dense_nn(q[:, :, :200], r, 1)
+    assert d.shape == (2, 1, 203) and np.array_equal(i[:, :, :57], i0[:, :, :57]) and np.all(i[1, :, 57:] == -1)
+    assert np.all(np.isinf(d[1, :, 57:])) and np.array_equal(d[0, :, :200], d0[0])
+
+
 def test_nn_pointers_off_the_16_byte_grid(pea):
     """Feature maps that start one or a few elements into an allocation (views into a larger
     buffer): the 16-byte loaders and LDS-direct paths must stand aside, results unchanged."""
