@@ -63,3 +63,22 @@ def test_no_kernel_spills_or_uses_scratch(tmp_path):
     bad = {k: v for k, v in kernels.items()
            if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, f"kernels with scratch memory or spilled vector registers: {bad}"
+
+
+def test_two_workgroups_per_cu_kernels_fit_their_registers(tmp_path):
+    """The 128-channel filter kernels run two 4-wave workgroups per CU (two waves per SIMD: 256 registers per lane
+    each); one register more and the second workgroup no longer fits, which halves the matrix-pipe utilisation
+    without changing a result."""
+    kernels = _kernel_metadata(tmp_path)
+
+    def regs(fragment):
+        hits = [v["vgpr_count"] for k, v in kernels.items() if fragment in k]
+        assert len(hits) == 1, (fragment, len(hits))
+        return hits[0]
+
+    assert regs("nn_filter_bf16_t16_kernelILi4ELi4E") <= 256
+    assert regs("nn_filter_split_kernelILi4E") <= 256
+    assert regs("nn_filter_f32_qreg_kernelILi8ELi1E") <= 256
+    assert regs("nn_filter_bf16_kernelILi8ELi5ELi2E") <= 256        # top-5, 128 channels
+    # the float64 batched pass keeps two waves per SIMD as well
+    assert regs("nn_exact_top1_kernelIfE") <= 256 and regs("nn_exact_top1_kernelItE") <= 256
