@@ -67,6 +67,12 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     # (n sampled correspondences, as the KNN layer gets them) is brought there by repeating the last query column:
     # queries are independent, the copies' results are dropped, and the call is about twice as fast as through
     # the guarded loaders.  (Reference columns cannot be padded: a made-up cell could win.)
+    # For k = 1 the reference map can be brought to a multiple of 8 the same way: copies of the last cell tie with it
+    # exactly, the exact index order names the lowest index of a tie - the real cell -, so no copy is ever returned
+    # (for k > 1 the copies would take the ranks behind it).
+    if k == 1 and nr % 8 and c % 32 == 0 and nr >= 8:
+        r = torch.cat([r, r[:, :, -1:].expand(b, c, 8 - nr % 8)], dim=2).contiguous()
+        nr = r.shape[2]
     n_real = nq
     if nq % 8 and nr % 8 == 0 and c % 32 == 0 and nq >= 8:
         q = torch.cat([q, q[:, :, -1:].expand(b, c, 8 - nq % 8)], dim=2).contiguous()

@@ -1032,6 +1032,13 @@ def test_nn_query_counts_off_the_8_cell_grid(pea):
                                     (2, 64, 77, 520, 5, "bf16"), (1, 128, 13, 784, 8, "f32"), (2, 128, 9, 1024, 1, "split")):
         q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
         _nn_check(pea, q, r, k, bf16=(mode == "bf16"), split=(mode == "split"))
+    # top-1 against reference maps off the grid (55x55, 63x63 cells): copies of the last cell pad the map and tie
+    # with it; queries whose nearest cell IS the last one must still get its index
+    for (b, c, nq, nr, mode) in ((2, 128, 512, 3025, "f32"), (2, 128, 999, 3969, "bf16"), (1, 64, 300, 1001, "split")):
+        q, r = _unit(rs, (b, c, nq)), _unit(rs, (b, c, nr))
+        q[:, :, 5] = r[:, :, nr - 1]                     # exact match with the last cell
+        q[:, :, 6] = r[:, :, nr - 1] + 1e-3 * q[:, :, 6]  # and a near match
+        _nn_check(pea, q, r, 1, bf16=(mode == "bf16"), split=(mode == "split"))
     # with the layer's query counts on top
     q, r = _unit(rs, (2, 128, 203)), _unit(rs, (2, 128, 1024))
     d, i = pea.correspondence.dense_nn(q, r, 1, num_query=[203, 57])
