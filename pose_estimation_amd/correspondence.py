@@ -28,7 +28,8 @@ def _workspace(nbytes):
     return ws
 
 
-def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native", num_query=None, normalize=False):
+def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native", num_query=None, normalize=False,
+             pad=True):
     """k nearest reference cells (squared L2) for every query column.
 
     query (B,C,Hq,Wq) or (B,C,n); ref (B,C,H,W) or (B,C,nr); float32, or bfloat16 torch tensors.
@@ -44,6 +45,10 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     normalize=True (float32 inputs): both maps pass through L2NormLayer.forward (l2norm_layer.py:18-29)
     inside the call, as the reference's net does in front of the KNN layer (train.prototxt:2096-2115); the
     result is that of dense_nn(l2norm(query), l2norm(ref), ...), bit for bit, without the extra passes.
+
+    pad=True: shapes off the grid of the fast kernels (channels not a multiple of 32, cell counts not multiples of
+    8) are padded up to it in ways that cannot change a result (see below); pad=False hands the arrays to the
+    library as they are (its guarded loaders take them: same results, slower).
 
     num_query (B,) or (B,1): the layer's `num_coord` bottom with `use_all_query: false`
     (train.prototxt:2128-2141) - only the first num_query[b] query columns of item b are real; the
@@ -67,14 +72,22 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     # (n sampled correspondences, as the KNN layer gets them) is brought there by repeating the last query column:
     # queries are independent, the copies' results are dropped, and the call is about twice as fast as through
     # the guarded loaders.  (Reference columns cannot be padded: a made-up cell could win.)
+    # Channel counts off the 32-channel grid of the MFMA filters: zero channels change no product, no norm and no
+    # float64 sum (fma(0, 0, s) == s), so both maps are padded with them (one copy of the inputs) and the call
+    # takes the fast kernels instead of the guarded loaders.
+    if pad and c % 32 and c < 256:
+        extra = 32 - c % 32
+        q = torch.cat([q, q.new_zeros(b, extra, nq)], dim=1)
+        r = torch.cat([r, r.new_zeros(b, extra, nr)], dim=1)
+        c += extra
     # For k = 1 the reference map can be brought to a multiple of 8 the same way: copies of the last cell tie with it
     # exactly, the exact index order names the lowest index of a tie - the real cell -, so no copy is ever returned
     # (for k > 1 the copies would take the ranks behind it).
-    if k == 1 and nr % 8 and c % 32 == 0 and nr >= 8:
+    if pad and k == 1 and nr % 8 and c % 32 == 0 and nr >= 8:
         r = torch.cat([r, r[:, :, -1:].expand(b, c, 8 - nr % 8)], dim=2).contiguous()
         nr = r.shape[2]
     n_real = nq
-    if nq % 8 and nr % 8 == 0 and c % 32 == 0 and nq >= 8:
+    if pad and nq % 8 and nr % 8 == 0 and c % 32 == 0 and nq >= 8:
         q = torch.cat([q, q[:, :, -1:].expand(b, c, 8 - nq % 8)], dim=2).contiguous()
         nq = q.shape[2]
     dist = dv.empty((b, k, nq), torch.float32)

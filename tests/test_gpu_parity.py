@@ -634,19 +634,24 @@ def test_zbuffer_config4_pose_sweep(pea):
 
 
 # ---------------------------------------------------------------- dense nearest neighbour
-def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False):
+def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False, pad=True):
     import torch
     b = q.shape[0]
+    off_grid = q.shape[1] % 32 or int(np.prod(q.shape[2:])) % 8 or int(np.prod(r.shape[2:])) % 8
+    if pad and off_grid:
+        # shapes off the grid of the fast kernels: also as they are, through the library's guarded loaders
+        _nn_check(pea, q, r, k, bf16=bf16, index_base=index_base, split=split, pad=False)
     if split:
-        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, filter="split-always")
+        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, filter="split-always",
+                                                    pad=pad)
     elif bf16:
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
-        dist, ind, st = pea.correspondence.dense_nn(qd, rd, k, index_base, return_stats=True)
+        dist, ind, st = pea.correspondence.dense_nn(qd, rd, k, index_base, return_stats=True, pad=pad)
         dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
         q, r = cnative.round_bf16(q), cnative.round_bf16(r)
     else:
-        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True)
+        dist, ind, st = pea.correspondence.dense_nn(q, r, k, index_base, return_stats=True, pad=pad)
     assert ind.dtype == np.int32 and dist.dtype == np.float32
     for i in range(b):
         want_i, want_d = cnative.nn_exact(q[i].reshape(q.shape[1], -1), r[i].reshape(r.shape[1], -1), k, index_base)

@@ -13,15 +13,16 @@ import pose_estimation_amd as pea                       # noqa: E402
 from oracle import cnative                              # noqa: E402
 
 
-def check(q, r, k, mode, index_base):
+def check(q, r, k, mode, index_base, pad=True):
     if mode == "bf16":
         qd = torch.from_numpy(q).cuda().to(torch.bfloat16)
         rd = torch.from_numpy(r).cuda().to(torch.bfloat16)
-        dist, ind = pea.correspondence.dense_nn(qd, rd, k, index_base)
+        dist, ind = pea.correspondence.dense_nn(qd, rd, k, index_base, pad=pad)
         dist, ind = dist.cpu().numpy(), ind.cpu().numpy()
         q, r = cnative.round_bf16(q), cnative.round_bf16(r)
     else:
-        dist, ind = pea.correspondence.dense_nn(q, r, k, index_base, filter="split-always" if mode == "split" else "native")
+        dist, ind = pea.correspondence.dense_nn(q, r, k, index_base, filter="split-always" if mode == "split" else "native",
+                                                pad=pad)
     for i in range(q.shape[0]):
         want_i, want_d = cnative.nn_exact(q[i], r[i], k, index_base)
         if not np.array_equal(ind[i], want_i):
@@ -45,6 +46,11 @@ def main():
         b = int(rs.randint(5, 9)) if big else int(rs.randint(1, 4))
         nq = 8 * int(rs.randint(300, 520)) if big else 8 * int(rs.randint(1, 300))
         nr = 8 * int(rs.randint(64, 700))
+        if rs.rand() < 0.3:                               # shapes off the grid of the fast kernels
+            nq += int(rs.randint(0, 8))
+            nr += int(rs.randint(0, 8))
+            c = int(rs.choice([c, 20, 48, 100, 144]))
+        pad = bool(rs.rand() < 0.7)                       # host-side padding up to the grid, or the library's guarded loaders
         style = int(rs.randint(0, 4))
         if style == 0:                                    # random unit vectors
             q, r = rs.randn(b, c, nq), rs.randn(b, c, nr)
@@ -62,10 +68,10 @@ def main():
         if style != 3:
             q /= np.sqrt((q ** 2).sum(1, keepdims=True))
             r /= np.sqrt((r ** 2).sum(1, keepdims=True))
-        err = check(q, r, k, mode, int(rs.randint(0, 2)))
+        err = check(q, r, k, mode, int(rs.randint(0, 2)), pad)
         cases += 1
         if err:
-            print(f"FAIL case {cases}: {err}; c={c} k={k} mode={mode} b={b} nq={nq} nr={nr} style={style} seed={seed}",
+            print(f"FAIL case {cases}: {err}; c={c} k={k} mode={mode} b={b} nq={nq} nr={nr} style={style} pad={pad} seed={seed}",
                   flush=True)
             sys.exit(1)
         if cases % 20 == 0:
