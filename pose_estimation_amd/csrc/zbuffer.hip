@@ -12,7 +12,7 @@
 // atomicMin per covered pixel; then visits them again to test each point that lands in the tile against
 // the finished tile (visibility; pass 1 leaves the tile offsets of the points it placed in LDS, so that
 // pass 2 recomputes only the depth of those points); then streams the tile to HBM once.  How many chunks a tile must visit
-// depends on the order of the points: correctness never does.  With a model's points in Morton order
+// depends on the order of the points: correctness never does.  With a model's points along a Hilbert curve
 // (run_proj.spatial_order, once per model) a chunk is a small blob on the screen and touches 1-2 tiles.
 #include "common.h"
 #include "geom_device.h"
@@ -234,7 +234,7 @@ __device__ __forceinline__ int zb_build_list(const short4 *__restrict__ box, int
         __syncthreads();
         const int total = cnt[0];
         __syncthreads();
-        if (threadIdx.x == 0) cnt[0] = 0;
+        if (threadIdx.x == 0) cnt[0] = 0;             // every wave has read the sum; the next add is behind a barrier
         if (total <= kListMax) {
             int at = 0;
             if (lane == 0 && mine) at = atomicAdd(&cnt[1], mine);
@@ -251,6 +251,7 @@ __device__ __forceinline__ int zb_build_list(const short4 *__restrict__ box, int
             return total;
         }
         rounds >>= 1;                                 // too many hits for the list: take fewer rounds
+        __syncthreads();                              // the reset above must land before any wave counts again
     }
 }
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kZThreads, kWgPerCu * kZThreads / 256) void zb_tile
     double relax, const short4 *__restrict__ box, const int4 *__restrict__ pose_box, int nchunks, int tiles_x,
     int tiles_y, int *__restrict__ counter, unsigned long long *__restrict__ packed, int32_t *__restrict__ winner,
     float *__restrict__ depth, uint8_t *__restrict__ truth, int vec_ok) {
-    __shared__ unsigned long long tile[kTileH * kTileW];
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[kTileH * kTileW];   // read as 16-byte pairs
     __shared__ int list[kListMax];
     __shared__ int cnt[2];
     __shared__ unsigned short pixcache[kCacheVisits * kChunk];

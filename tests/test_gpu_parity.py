@@ -633,6 +633,35 @@ def test_zbuffer_config4_pose_sweep(pea):
         assert 20000 < int(vis.sum()) < 100000
 
 
+@pytest.mark.parametrize("n,radius", [(100000, 0), (100000, 2), (150000, 0), (150000, 1)])
+def test_project_zbuffer_unsorted_large_models(pea, n, radius):
+    """Points in the reference's own (random) sampling order: every chunk of 64 consecutive points spans the whole
+    object, so an object tile is hit by all 1563 (100k points) or 2344 (150k) chunks.  That is more than the
+    1024 entries of the tile's chunk list: the list is built in several segments, each after the first attempt to
+    take four rounds of boxes overflowed and was retried with fewer.  Keys, winners, depths and flags bit-exact
+    against the oracle; two runs give the same bits."""
+    rs = np.random.RandomState(97 + n // 1000 + radius)
+    pts = rs.uniform(-0.4, 0.4, (n, 3))
+    pts[::2] *= np.array([1.0, 0.25, 1.0])             # a denser slab, so depths collide
+    poses = np.array([[30.0, 10.0, 0.0, 3.0], [250.0, 35.0, 5.0, 2.0]])
+    cams = pea.pt2render.camera_matrices(poses)
+    want = ("packed", "winner", "depth", "truth")
+    got = pea.zbuffer.project_zbuffer(pts, cams, (540, 960), radius=radius, relax=0.01, want=want)
+    again = pea.zbuffer.project_zbuffer(pts, cams, (540, 960), radius=radius, relax=0.01, want=want)
+    for key in want:
+        assert np.array_equal(got[key], again[key]), key
+    for p in range(len(poses)):
+        render, key, win, depth, vis = _zb_oracle(pts, cams[p], 540, 960, radius, 0.01)
+        assert np.array_equal(got["packed"][p].view(np.uint64), key), (n, radius, p)
+        assert np.array_equal(got["winner"][p], win) and np.array_equal(got["depth"][p], depth)
+        assert np.array_equal(got["truth"][p], vis)
+        assert int(vis.sum()) > 5000
+    # the same through projected coordinates (chunk boxes from the pixels themselves)
+    render = pea.pt2render.get_render_location(pts, cams)
+    got2 = pea.zbuffer.project_zbuffer(None, None, radius=radius, relax=0.01, want=("packed", "truth"), pt_render=render)
+    assert np.array_equal(got2["packed"], got["packed"]) and np.array_equal(got2["truth"], got["truth"])
+
+
 # ---------------------------------------------------------------- dense nearest neighbour
 def _nn_check(pea, q, r, k, bf16=False, index_base=1, split=False, pad=True):
     import torch

@@ -40,15 +40,17 @@ def _kernel_metadata(tmp_path):
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={piece}", f"--output={elf}"])
         notes = subprocess.run([tools["llvm-readelf"], "--notes", str(elf)], check=True, capture_output=True,
                                text=True).stdout
-        name = None
+        name, pending_lds = None, 0
         for line in notes.splitlines():
             m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)", line)
             if not m:
                 continue
             key, val = m.groups()
-            if key == "name" and val.startswith("_Z"):
+            if key == "group_segment_fixed_size":            # listed in front of the kernel's name
+                pending_lds = int(val)
+            elif key == "name" and val.startswith("_Z"):
                 name = val
-                kernels[name] = {}
+                kernels[name] = {"group_segment_fixed_size": pending_lds}
             elif name and key in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count"):
                 kernels[name][key] = int(val)
     return kernels
@@ -82,3 +84,14 @@ def test_two_workgroups_per_cu_kernels_fit_their_registers(tmp_path):
     assert regs("nn_filter_bf16_kernelILi8ELi5ELi2E") <= 256        # top-5, 128 channels
     # the float64 batched pass keeps two waves per SIMD as well
     assert regs("nn_exact_top1_kernelIfE") <= 256 and regs("nn_exact_top1_kernelItE") <= 256
+
+
+def test_tiled_zbuffer_keeps_two_workgroups_per_cu(tmp_path):
+    """zb_tile_kernel overlaps the phases of two resident workgroups; its static LDS (key tile, chunk list, pixel
+    cache) must leave room for two in a CU's 160 KiB, and its 512-thread workgroups for two in the register file."""
+    kernels = _kernel_metadata(tmp_path)
+    hits = {k: v for k, v in kernels.items() if "zb_tile_kernel" in k}
+    assert len(hits) == 2, list(hits)
+    for name, meta in hits.items():
+        assert 0 < meta["group_segment_fixed_size"] <= 160 * 1024 // 2, (name, meta)
+        assert meta["vgpr_count"] <= 128, (name, meta)
