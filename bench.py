@@ -7,7 +7,7 @@ dense nearest-neighbour correspondence between a 64x64 grid of 128-d query featu
 finalize, float64 exact pass).  With N GPUs each rank holds its own batch (weak scaling, no
 collective in the data path) and the index/distance records are all-gathered once per step.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' with ranks sharing one GPU rehearses the multi-rank "
                          "code path on a single-GPU box (not a measurement)")
+    ap.add_argument("--depth-per-pose", action="store_true",
+                    help="project: every pose tests visibility against a depth map of its own (P x 540 x 960 float32, "
+                         "as make_disparity uses them: one render per pose) instead of one map shared by all poses, "
+                         "so that the depth gathers come from HBM rather than from L2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the side measurements of the default run (bfloat16 / split filter / close matches, and "
@@ -235,19 +239,21 @@ def run_geometry(args, torch, dist, world, rank, dev):
         else:
             poses = np.resize(poses, (P, 4))
         cams = torch.from_numpy(pea.pt2render.camera_matrices(poses)).to(dev)
-        depth = torch.full((540, 960), 3.0, dtype=torch.float32, device=dev)
+        per_pose = 1 if getattr(args, "depth_per_pose", False) else 0
+        depth = torch.full((P, 540, 960) if per_pose else (540, 960), 3.0, dtype=torch.float32, device=dev)
         out = torch.empty((P, 3, n), dtype=torch.float64, device=dev)
         truth = torch.empty((P, n), dtype=torch.uint8, device=dev)
 
         def step():
-            _abi.check(_abi.lib.ispa_project_prune(pts.data_ptr(), n, cams.data_ptr(), P, depth.data_ptr(), 0, 540,
+            _abi.check(_abi.lib.ispa_project_prune(pts.data_ptr(), n, cams.data_ptr(), P, depth.data_ptr(), per_pose, 540,
                                                    960, 540, 950, 0.15, _abi.VIS_A, crop_one.data_ptr(), 0,
                                                    out.data_ptr(), truth.data_ptr(), None, None, st()))
         units, unit_name, recs = P, "pose-maps/s", 1
         alg_bytes = [24.0 * n + 29.0 * n * P]
         names = ["project_prune"]
         workload = (f"projection + depth visibility (variant A) + crop remap of a {n}-point model at {P} poses "
-                    f"per GPU per step, float64 drop-in layout")
+                    f"per GPU per step, float64 drop-in layout, "
+                    + ("one depth map per pose" if per_pose else "one depth map shared by all poses"))
     elif args.workload == "corr":
         from pose_estimation_amd import correspondence as co
         bsz, views, kpts = 8, 3, 10                     # multi_view_configs/train_config.py: batch 8, 3 views
@@ -415,6 +421,11 @@ def run_geometry(args, torch, dist, world, rank, dev):
          "make_disparity_ws": "disparity_points_kernel+disparity_bands_kernel"}[names[dom]],
         args.workload == "corr" or (n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
                                                       else args.maps == 256)))
+    if getattr(args, "depth_per_pose", False):
+        traffic, traffic_src = None, None                # the committed counter passes ran with one shared depth map
+    if traffic:
+        # the profile's counter bytes over THIS run's kernel time: the rate HBM really delivered
+        roof["hbm_frac_counter"] = round(traffic / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out_json = {
         "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"],
         "value": round(units * world * args.steps / elapsed, 2), "unit": unit_name, "n_gpus": world,
@@ -433,29 +444,65 @@ def run_geometry(args, torch, dist, world, rank, dev):
     return out_json
 
 
+def disparity_step(torch, dev, maps, n, model, seed):
+    """One make_disparity call for `maps` renders of an n-point model, as the `disparity` workload runs it (points
+    along a Hilbert curve ranked as generated, one depth map per render): (step function, buffers to keep alive)."""
+    import pose_estimation_amd as pea
+    from pose_estimation_amd import _abi, _device as dv
+    rs = np.random.RandomState(seed)
+    pts_np = synthetic_model(model, n, seed)
+    params = np.stack([rs.uniform(0, 360, maps), rs.uniform(-10, 35, maps), np.zeros(maps), np.full(maps, 3.0)], axis=1)
+    cams1 = torch.from_numpy(pea.pt2render.camera_matrices(params)).to(dev)
+    more = params.copy()
+    more[:, :2] += 10.0
+    cams2 = torch.from_numpy(pea.pt2render.camera_matrices(more)).to(dev)
+    depth = torch.full((maps, 540, 960), 3.0, dtype=torch.float32, device=dev)
+    crops = torch.tensor([[100, 400, 300, 700]], dtype=torch.int32, device=dev).repeat(maps, 1).contiguous()
+    flow = torch.empty((maps, 224, 224, 2), dtype=torch.float64, device=dev)
+    need = _abi.lib.ispa_make_disparity_workspace_bytes(n, maps)
+    dws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+    po = pea.disparity.PointOrder(pts_np)
+
+    def step():
+        _abi.check(_abi.lib.ispa_make_disparity_ordered(
+            po.points.data_ptr(), po.rank.data_ptr(), po.inverse.data_ptr(), n, cams1.data_ptr(), cams2.data_ptr(),
+            maps, depth.data_ptr(), 1, 540, 960, 540, 950, 0.15, crops.data_ptr(), 1, 2, flow.data_ptr(),
+            dws.data_ptr(), need, dv.stream_ptr()))
+    return step, (cams1, cams2, depth, crops, flow, dws, po)
+
+
 def stage_records(args, torch, dist, dev):
     """The other stages of the path at their BASELINE sizes, a few steps each, for the `extra.stages` block of the
     default run (one GPU): the same measurement code as `--workload <stage>`, trimmed to the fields that say what
     ran and how close to its roofline.  Not part of `value`."""
     import copy
     out = {}
-    for wl in ("project", "zbuffer", "disparity", "corr"):
+    for key in ("project", "project_depth_per_pose", "zbuffer", "disparity", "corr"):
+        wl = "project" if key.startswith("project") else key
         a = copy.copy(args)
         # ten warm-up steps: the first half dozen launches over freshly allocated output buffers of several GB run
         # 10-15 % slower than the steady state (measured on the projection stage: 1.98 ms against 1.74 ms)
-        a.workload, a.steps, a.warmup, a.no_cpu_baseline = wl, 10, 10, True
+        a.workload, a.steps, a.warmup = wl, 10, 10
         a.poses, a.maps, a.points, a.model, a.unfused, a.one_launch, a.morton = 3600, 256, 100000, "chair", False, False, False
         a.as_generated = False
+        a.depth_per_pose = key == "project_depth_per_pose"
+        # a bounded CPU sample beside every geometry stage (the reference-shaped loops); the correlation stage
+        # and the second projection line (same CPU work as the first) go without
+        a.no_cpu_baseline = args.no_cpu_baseline or key in ("corr", "project_depth_per_pose")
+        a.cpu_seconds = 4.0
         rec = run_geometry(a, torch, dist, 1, 0, dev)
         roof = rec["roofline"]
-        out[wl] = {"value": rec["value"], "unit": rec["unit"], "steps": a.steps, "ms_per_step": rec["ms_per_step"],
-                   "dtype": rec["dtype"], "workload": rec["config"]["workload"],
-                   "point_order": rec["config"]["point_order"],
-                   "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms",
-                                                     "frac_of_fill", "measured_fill_gbs") if k in roof}}
+        out[key] = {"value": rec["value"], "unit": rec["unit"], "steps": a.steps, "ms_per_step": rec["ms_per_step"],
+                    "dtype": rec["dtype"], "workload": rec["config"]["workload"],
+                    "point_order": rec["config"]["point_order"],
+                    "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "hbm_frac_counter",
+                                                      "traffic", "traffic_source", "kernel", "kernel_ms",
+                                                      "frac_of_fill", "measured_fill_gbs") if k in roof}}
+        if "cpu_baseline" in rec:
+            out[key]["cpu_baseline"] = rec["cpu_baseline"]
         if wl == "corr":
-            out[wl]["note"] = ("66 KB-sized problem of five dependent launches: latency-bound at the reference's "
-                               "shapes, the HBM fraction says only that no bandwidth is needed")
+            out[key]["note"] = ("66 KB-sized problem of five dependent launches: latency-bound at the reference's "
+                                "shapes, the HBM fraction says only that no bandwidth is needed")
         torch.cuda.empty_cache()
     return out
 
@@ -659,6 +706,19 @@ def main():
 
     default_shape = (b, g, c, args.k, args.dtype, filt) == (512, 64, 128, 1, "f32", "native") and not args.matches
     if world == 1 and default_shape and not args.no_extra:
+        # The metric names correspondence AND disparity maps: per image pair one dense NN correspondence and one
+        # make_disparity flow map (100k-point model) in the same timed region, back to back on one stream.
+        disp, keep = disparity_step(torch, dev, b, 100000, "chair", 300)
+        q16, r16 = q.to(torch.bfloat16), r.to(torch.bfloat16)
+        combined = {"unit": "pairs/s", "steps": 10,
+                    "workload": f"per pair one dense NN correspondence ({g}x{g}x{c}, k=1) + one make_disparity flow "
+                                f"map (224x224x2 float64, 100000-point model), {b} pairs per step"}
+        for tag, fn in (("f32", lambda: (pea.correspondence.dense_nn(q, r, 1), disp())),
+                        ("bf16", lambda: (pea.correspondence.dense_nn(q16, r16, 1), disp()))):
+            elc, _ = side_run(fn, 10)
+            combined[tag] = {"value": round(b * 10 / elc, 2), "ms_per_step": round(elc / 10 * 1e3, 4)}
+        extra["combined"] = combined
+        del q16, r16, disp, keep
         del q, r
         torch.cuda.empty_cache()
         extra["stages"] = stage_records(args, torch, dist, dev)

@@ -50,6 +50,27 @@ def golden_correlation_acmm():
 
 
 @pytest.fixture(scope="session")
+def golden_nn_crosspin():
+    return np.load(os.path.join(GOLDEN, "nn_crosspin.npz"))
+
+
+def crosspin_cases(z, tag, k):
+    """Per item of a nn_crosspin.npz case: (queries (C, 784) = template cells, references (C, 784), wanted
+    1-based indices (k, 784), mask (784,) of the template cells whose ranking is decided).  The reference's map
+    values are float32 dot products of unit vectors scaled by one positive number per map, so a ranking counts as
+    decided when every gap among its first k + 1 values exceeds 1e-4 of the best value (a few hundred float32
+    ulps of a dot product, far above what the order of summation can move)."""
+    f1, f2 = z[f"{tag}_f1"], z[f"{tag}_f2"]
+    top, val = z[f"{tag}_top6"].astype(np.int64), z[f"{tag}_top6_values"].astype(np.float64)
+    b, c = f1.shape[:2]
+    for i in range(b):
+        gaps = val[i, :, :k] - val[i, :, 1:k + 1]
+        decided = (val[i, :, 0] > 0) & (gaps > 1e-4 * val[i, :, :1]).all(axis=1)
+        yield (np.ascontiguousarray(f2[i].reshape(c, 784)), np.ascontiguousarray(f1[i].reshape(c, 784)),
+               np.ascontiguousarray(top[i, :, :k].T + 1), decided)
+
+
+@pytest.fixture(scope="session")
 def golden_tables():
     import json
     with open(os.path.join(GOLDEN, "tables.json")) as fh:

@@ -10,7 +10,8 @@ What is imported from the reference, unmodified:
   classifier_code/train_test_scripts/utils/pt2render.py  -> ref_b  (variant B visibility)
   classifier_code/train_test_scripts/arch/eccv_net/eccv_net.py -> CorrelationMapLayer.forward,
       called unbound on CPU with a stub `self` that only carries `down1` (the class
-      constructor calls .cuda()).
+      constructor calls .cuda()).  The same call on unit-norm 28x28 maps with every template cell as a
+      keypoint gives the dense nearest-neighbour search its reference-produced ranking (nn_crosspin.npz).
   classifier_code/train_test_scripts/arch/acmm_net/net_final_old.py -> CorrelationMapLayer.forward,
       called unbound on CPU the same way; the stub's `inception00` / `bn00` (the trained trunk
       behind the correlation, lines 63-64) are identities, and torch.Tensor.cuda is patched to
@@ -368,6 +369,44 @@ def gen_correlation():
     print("correlation.npz", len(out), "arrays")
 
 
+def gen_nn_crosspin():
+    """A reference-produced pin for the dense nearest-neighbour search.  The KNN layer itself is external, but the
+    reference's own all-pairs contraction (eccv_net.py:193-210) ranks the cells of feature1 for every template
+    cell of feature2 by dot product; on L2-normalised features that is the ranking by L2 distance
+    (d^2 = |q|^2 + |r|^2 - 2 q.r).  The layer is run on CPU, unbound, on 28x28 unit-norm maps with the resize
+    stub replaced by the identity (the maps already have the layer's working size) and ALL 784 template cells as
+    keypoints; per (item, template cell) the six best cells of its output map and their values are stored.  The
+    normalisation x / sum(exp(x)) * 10 scales a whole map by one positive number, so the order is the
+    contraction's own."""
+    import torch
+    sys.path.insert(0, f"{REF}/classifier_code")
+    eccv = importlib.import_module("train_test_scripts.arch.eccv_net.eccv_net")
+    stub = types.SimpleNamespace(down1=lambda x: x)
+    out = {}
+    rs = np.random.RandomState(23)
+    yy, xx = np.mgrid[0:28, 0:28]
+    knn = np.stack([xx.ravel(), yy.ravel()], axis=1).astype(np.int64)      # [x, y]: row p = cell y*28+x
+    for tag, (b, c) in {"b1c128": (1, 128), "b2c64": (2, 64)}.items():
+        f1 = rs.randn(b, c, 28, 28).astype(np.float32)
+        f2 = rs.randn(b, c, 28, 28).astype(np.float32)
+        # a related pair, like a real image and its template: f2 = noisy, shifted copy of f1 for half the cells
+        f2[:, :, :14] = 0.8 * np.roll(f1, 1, axis=3)[:, :, :14] + 0.6 * f2[:, :, :14]
+        f1 /= np.sqrt((f1 ** 2).sum(1, keepdims=True, dtype=np.float32))
+        f2 /= np.sqrt((f2 ** 2).sum(1, keepdims=True, dtype=np.float32))
+        with torch.no_grad():
+            res = eccv.CorrelationMapLayer.forward(stub, torch.from_numpy(f1), torch.from_numpy(f2),
+                                                   torch.from_numpy(knn))
+        res = np.asarray(res.data if hasattr(res, "data") else res).reshape(b, 784, 784)   # [item, template cell, cell of f1]
+        order = np.argsort(-res, axis=2, kind="stable")[:, :, :6]
+        out[f"{tag}_f1"] = f1
+        out[f"{tag}_f2"] = f2
+        out[f"{tag}_top6"] = order.astype(np.int16)
+        out[f"{tag}_top6_values"] = np.take_along_axis(res, order, axis=2).astype(np.float32)
+        print(tag, "positive maps", int((res.max(axis=2) > 0).sum()), "of", b * 784)
+    np.savez_compressed(os.path.join(HERE, "nn_crosspin.npz"), **out)
+    print("nn_crosspin.npz", len(out), "arrays")
+
+
 def gen_acmm():
     import torch
     sys.path.insert(0, f"{REF}/classifier_code")
@@ -468,7 +507,9 @@ def gen_exr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables", "exr", "demo_flow"]
+    which = sys.argv[1:] or ["geometry", "disparity", "correlation", "acmm", "tables", "exr", "demo_flow", "nn_crosspin"]
+    if "nn_crosspin" in which:
+        gen_nn_crosspin()
     if "demo_flow" in which:
         gen_demo_flow()
     if "exr" in which:

@@ -721,6 +721,38 @@ def test_nn_fused_l2norm_prologue(pea):
                                     torch.zeros(1, 32, 8, device="cuda", dtype=torch.bfloat16), normalize=True)
 
 
+@pytest.mark.parametrize("tag", ["b1c128", "b2c64"])
+@pytest.mark.parametrize("k", [1, 5])
+def test_nn_against_the_reference_contraction(pea, golden_nn_crosspin, tag, k):
+    """dense_nn against numbers the reference produced: the ranking of feature1's cells for every template cell
+    by the reference's own all-pairs contraction (eccv_net.py:193-210; tests/golden/nn_crosspin.npz).  float32
+    (both filters): the reference's best cell / five best cells in order wherever its float32 values decide them.
+    bfloat16: the same wherever the gaps also exceed the bfloat16 rounding of the inputs (2^-7 of the best value)."""
+    import torch
+    from conftest import crosspin_cases
+    z = golden_nn_crosspin
+    for q, r, want, decided in crosspin_cases(z, tag, k):
+        for flt in ("native", "split-always"):
+            dist, ind = pea.correspondence.dense_nn(q[None], r[None], k, 1, filter=flt)
+            assert np.array_equal(ind[0][:, decided], want[:, decided]), flt
+            # d^2 = 2 - 2 q.r on unit vectors: ascending distances = the reference's descending values
+            assert np.all(np.diff(dist[0], axis=0) >= 0)
+        # through the C ABI as it is (no padding of the 784-cell maps by the Python layer)
+        dist, ind = pea.correspondence.dense_nn(q[None], r[None], k, 1, pad=False)
+        assert np.array_equal(ind[0][:, decided], want[:, decided])
+    top, val = z[f"{tag}_top6"].astype(np.int64), z[f"{tag}_top6_values"].astype(np.float64)
+    f1, f2 = z[f"{tag}_f1"], z[f"{tag}_f2"]
+    b, c = f1.shape[:2]
+    qd = torch.from_numpy(f2.reshape(b, c, 784)).cuda().to(torch.bfloat16)
+    rd = torch.from_numpy(f1).cuda().to(torch.bfloat16)
+    dist, ind = pea.correspondence.dense_nn(qd, rd, k, 1)
+    ind = ind.cpu().numpy()
+    wide = (val[:, :, 0] > 0) & ((val[:, :, :k] - val[:, :, 1:k + 1]) > 2.0 ** -7 * val[:, :, :1]).all(axis=2)
+    assert wide.sum() > (100 if k == 1 else 3)
+    for i in range(b):
+        assert np.array_equal(ind[i][:, wide[i]], (top[i, :, :k].T + 1)[:, wide[i]])
+
+
 @pytest.mark.parametrize("k", [1, 5, 8])
 def test_nn_small_ragged(pea, k):
     rs = np.random.RandomState(k)

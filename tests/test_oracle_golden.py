@@ -403,3 +403,24 @@ def test_hard_negative_rule_by_hand():
     assert mask.tolist() == [[False, False, True, False]]
     assert np.array_equal(xy[0], [[4, 4], [0, 0], [12, 12], [8, 8]])
     assert kp.hard_negatives(ind, corr, 4, thresh=3.9)[0].tolist() == [[False, True, True, False]]
+
+
+@pytest.mark.parametrize("tag", ["b1c128", "b2c64"])
+@pytest.mark.parametrize("k", [1, 5])
+def test_nn_oracle_against_the_reference_contraction(golden_nn_crosspin, tag, k):
+    """The dense nearest-neighbour contract against numbers the reference itself produced: its all-pairs
+    contraction (eccv_net.py:193-210, run unbound on CPU by tests/golden/make_golden.py) ranks the cells of
+    feature1 for every template cell by dot product, which on unit-norm features is the ranking by L2 distance.
+    Both restatements of the contract (numpy and C) must return the reference's best cell (k = 1) and its five
+    best cells in order (k = 5) wherever the reference's own float32 values decide the ranking."""
+    from conftest import crosspin_cases
+    from oracle import cnative, nn as onn
+    checked = 0
+    for q, r, want, decided in crosspin_cases(golden_nn_crosspin, tag, k):
+        ind_np, dist_np = onn.nn_exact_numpy(q, r, k, 1)
+        ind_c, dist_c = cnative.nn_exact(q, r, k, 1)
+        assert np.array_equal(ind_np, ind_c) and np.array_equal(dist_np, dist_c)
+        assert np.array_equal(ind_c[:, decided], want[:, decided])
+        assert decided.mean() > (0.97 if k == 1 else 0.85)
+        checked += int(decided.sum())
+    assert checked > 600
