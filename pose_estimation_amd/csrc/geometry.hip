@@ -6,7 +6,6 @@
 //   pt2render.py:18-38  crop: subtract, multiply, add pad, rint -- separate roundings (this
 //                       file is compiled with -ffp-contract=off; every fused op is explicit)
 //   pt2render.py:43-55  (A) and classifier_code/.../utils/pt2render.py:43-53 (B) visibility
-#include <cstdlib>
 #include "common.h"
 #include "geom_device.h"
 
@@ -218,7 +217,6 @@ int check_depth_args(const float *depth, int H, int W, int ylim, int xlim, int v
 // Poses per block: enough blocks to fill the chip, while re-using each loaded point.
 int pick_poses_per_block(int64_t n, int n_pose) {
     const int64_t point_blocks = (n + kThreads - 1) / kThreads;
-    if (const char *e = getenv("ISPA_DEV_PPB")) return atoi(e);
     int ppb = 1;
     while (ppb < 16 && point_blocks * ((n_pose + 2 * ppb - 1) / (2 * ppb)) >= 2048) ppb *= 2;
     return ppb;
