@@ -20,6 +20,7 @@ ISPA_ABI_VERSION = 1
 VIS_A, VIS_B = 0, 1
 F32, BF16, F32_SPLIT, F32_SPLIT_ALWAYS = 0, 1, 2, 3
 NN_NORMALIZE = 256
+NN_NO_PAD = 512
 PCK_MAX_RADII = 8
 PRUNE_POLYGON, PRUNE_BAND, PRUNE_DROP = 1, 2, 4
 PRUNE_MAX_VERTICES, PRUNE_MAX_SEGMENTS = 64, 256

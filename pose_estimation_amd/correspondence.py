@@ -46,9 +46,10 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     inside the call, as the reference's net does in front of the KNN layer (train.prototxt:2096-2115); the
     result is that of dense_nn(l2norm(query), l2norm(ref), ...), bit for bit, without the extra passes.
 
-    pad=True: shapes off the grid of the fast kernels (channels not a multiple of 32, cell counts not multiples of
-    8) are padded up to it in ways that cannot change a result (see below); pad=False hands the arrays to the
-    library as they are (its guarded loaders take them: same results, slower).
+    pad=True: the library brings shapes off the grid of its fast kernels (channels not a multiple of 32, cell
+    counts not multiples of 8) onto it inside the call, in ways that cannot change a result (zero channels,
+    repeated query columns whose results are dropped, reference cells no query can select); pad=False
+    (ISPA_NN_NO_PAD) makes it take the arrays as they are (guarded loaders: same results, slower).
 
     num_query (B,) or (B,1): the layer's `num_coord` bottom with `use_all_query: false`
     (train.prototxt:2128-2141) - only the first num_query[b] query columns of item b are real; the
@@ -68,28 +69,6 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     nq, nr = q.shape[2], r.shape[2]
     if not 1 <= k <= 8:
         raise ValueError("k must be in [1, 8]")
-    # The fast filter kernels take cell counts that are multiples of 8 (16-byte rows).  A query count that is not
-    # (n sampled correspondences, as the KNN layer gets them) is brought there by repeating the last query column:
-    # queries are independent, the copies' results are dropped, and the call is about twice as fast as through
-    # the guarded loaders.  (Reference columns cannot be padded: a made-up cell could win.)
-    # Channel counts off the 32-channel grid of the MFMA filters: zero channels change no product, no norm and no
-    # float64 sum (fma(0, 0, s) == s), so both maps are padded with them (one copy of the inputs) and the call
-    # takes the fast kernels instead of the guarded loaders.
-    if pad and c % 32 and c < 256:
-        extra = 32 - c % 32
-        q = torch.cat([q, q.new_zeros(b, extra, nq)], dim=1)
-        r = torch.cat([r, r.new_zeros(b, extra, nr)], dim=1)
-        c += extra
-    # For k = 1 the reference map can be brought to a multiple of 8 the same way: copies of the last cell tie with it
-    # exactly, the exact index order names the lowest index of a tie - the real cell -, so no copy is ever returned
-    # (for k > 1 the copies would take the ranks behind it).
-    if pad and k == 1 and nr % 8 and c % 32 == 0 and nr >= 8:
-        r = torch.cat([r, r[:, :, -1:].expand(b, c, 8 - nr % 8)], dim=2).contiguous()
-        nr = r.shape[2]
-    n_real = nq
-    if pad and nq % 8 and nr % 8 == 0 and c % 32 == 0 and nq >= 8:
-        q = torch.cat([q, q[:, :, -1:].expand(b, c, 8 - nq % 8)], dim=2).contiguous()
-        nq = q.shape[2]
     dist = dv.empty((b, k, nq), torch.float32)
     ind = dv.empty((b, k, nq), torch.int32)
     stats = torch.zeros(4, dtype=torch.int32, device=dv.device()) if return_stats else None
@@ -98,6 +77,8 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
         if bf16:
             raise ValueError("normalize=True takes float32 features")
         code |= _abi.NN_NORMALIZE
+    if not pad:
+        code |= _abi.NN_NO_PAD
     key = (code, b, c, nq, nr, k)
     need = _ws_bytes.get(key)
     if need is None:
@@ -106,17 +87,14 @@ def dense_nn(query, ref, k=1, index_base=1, return_stats=False, filter="native",
     _abi.check(_abi.lib.ispa_nn_topk(dv.ptr(q), dv.ptr(r), code, b, c, nq, nr, k,
                                      int(index_base), dv.ptr(dist), dv.ptr(ind), dv.ptr(ws), ws.numel(),
                                      dv.ptr(stats), dv.stream_ptr()))
-    if n_real != nq:
-        dist, ind = dist[:, :, :n_real].contiguous(), ind[:, :, :n_real].contiguous()
-        nq = n_real
     if num_query is not None:
         nv = dv.to_dev(np.asarray(num_query).reshape(-1) if not dv.is_tensor(num_query) else num_query.reshape(-1),
                        torch.int64)
         if nv.numel() != b:
             raise ValueError("num_query must hold one count per batch item")
-        pad = torch.arange(nq, device=nv.device)[None, None, :] >= nv[:, None, None]
-        ind.masked_fill_(pad, -1)
-        dist.masked_fill_(pad, float("inf"))
+        unreal = torch.arange(nq, device=nv.device)[None, None, :] >= nv[:, None, None]
+        ind.masked_fill_(unreal, -1)
+        dist.masked_fill_(unreal, float("inf"))
     out = (dv.back(dist, as_tensor), dv.back(ind, as_tensor))
     if return_stats:
         st = stats.cpu().tolist()

@@ -95,6 +95,15 @@ __device__ __forceinline__ bool depth_test(double u, double v, double z,
     }
 }
 
+// double -> int32 with the hardware's own rule for every input: truncation, saturation at the int32 range, 0 for
+// NaN.  A C++ cast is undefined for values outside the range (the optimiser may assume they never occur), and
+// the callers convert lanes whose coordinates are garbage before they mask them out.
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // rint(a / b) with the IEEE division's result, at a fraction of its cost: a reciprocal refined by
 // two Newton steps gives the quotient to a few ulp, which rounds to the same integer as the
 // correctly rounded quotient unless it lies within 1e-5 of a half-integer (or is huge / not

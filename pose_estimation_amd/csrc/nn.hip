@@ -201,9 +201,21 @@ int launch_bf16_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const ui
     }
 }
 
+// Reference cells [nr_valid, nr) of every pair are padding (see nn_topk_checked): unselectable for the filters
+// (their accumulators start at the score of a masked cell) and at distance +inf for the float64 passes.
+__global__ void nn_mask_padding_kernel(float *__restrict__ rnh, double *__restrict__ r64, int B, int64_t nr,
+                                       int64_t nr_valid) {
+    const int64_t npad = nr - nr_valid;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * npad) return;
+    const int64_t o = (t / npad) * nr + nr_valid + t % npad;
+    rnh[o] = kNegInf;
+    r64[o] = __builtin_inf();
+}
+
 template <typename T>
-int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int index_base, float *dist,
-        int32_t *idx, char *ws, const Plan &p, int32_t *stats, hipStream_t s) {
+int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr_valid, int k, int index_base,
+        float *dist, int32_t *idx, char *ws, const Plan &p, int32_t *stats, hipStream_t s) {
     float *qnh = (float *)(ws + p.off_qnh);
     float *rnh = (float *)(ws + p.off_rnh);
     double *q64 = (double *)(ws + p.off_q64);
@@ -271,6 +283,9 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
         }
     }
     if (int rc = ispa::check_launch("nn_norms_kernel")) return rc;
+    if (nr_valid < nr)
+        hipLaunchKernelGGL(nn_mask_padding_kernel, dim3(ispa::blocks_for((int64_t)B * (nr - nr_valid), 256)), dim3(256), 0,
+                           s, rnh, r64, B, nr, nr_valid);
 
     const int64_t nblocks = (int64_t)B * p.nsplit * p.n_qtiles;
     ISPA_REQUIRE(nblocks < (1ll << 31), "problem too large for one launch");
@@ -368,8 +383,8 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
 
     if (small) {
         hipLaunchKernelGGL((nn_finalize_small_kernel<T>), dim3(ispa::blocks_for(nq, 64), B), dim3(64 * kFsWaves), 0, s,
-                           pval, pidx, p.nparts, qnh, C, nq, nr, index_base, err_rel, tag_rel, q, r, q64, r64, dist, idx, count,
-                           list, pcount, plist, count + 1);
+                           pval, pidx, p.nparts, qnh, C, nq, nr, nr_valid, index_base, err_rel, tag_rel, q, r, q64, r64, dist, idx,
+                           count, list, pcount, plist, count + 1);
         if (int rc = ispa::check_launch("nn_finalize_small_kernel")) return rc;
     }
     const dim3 fgrid(ispa::blocks_for(nq, 256), B);
@@ -446,25 +461,104 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int k, int
     return ISPA_OK;
 }
 
+// Shapes off the grid of the fast kernels (channels a multiple of 32, cell counts multiples of 8: 16-byte rows)
+// are brought onto it inside the call, in the workspace: zero channels (no product, norm or float64 sum changes),
+// copies of the last query column (queries are independent; the copies' results are dropped) and copies of the
+// last reference column that nn_mask_padding_kernel makes unselectable for any k.  ISPA_NN_NO_PAD hands the
+// arrays to the kernels as they are (guarded loaders).
+struct PadPlan {
+    bool on;
+    int Cp;
+    int64_t nqp, nrp;
+    bool copy_q, copy_r, tmp_out;
+    size_t inner, off_q, off_r, off_dist, off_idx, total;
+};
+
+PadPlan make_pad_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k) {
+    PadPlan pp;
+    const int dtype = dtype_and_flags & ~(ISPA_NN_NORMALIZE | ISPA_NN_NO_PAD);
+    const int inner_flags = dtype_and_flags & ISPA_NN_NORMALIZE;
+    const size_t elem = dtype == ISPA_BF16 ? 2 : 4;
+    pp.Cp = (C + 31) / 32 * 32;
+    pp.nqp = (nq + 7) / 8 * 8;
+    pp.nrp = (nr + 7) / 8 * 8;
+    // bfloat16 beyond 256 channels runs through the converting float32 loader whatever the shape
+    const bool reachable = dtype == ISPA_BF16 ? pp.Cp <= 256 : true;
+    pp.on = !(dtype_and_flags & ISPA_NN_NO_PAD) && reachable && nr >= k && pp.nrp < (1 << 27) &&
+            (pp.Cp != C || pp.nqp != nq || pp.nrp != nr);
+    if (!pp.on) {
+        pp.Cp = C;
+        pp.nqp = nq;
+        pp.nrp = nr;
+    }
+    pp.copy_q = pp.on && (pp.Cp != C || pp.nqp != nq);
+    pp.copy_r = pp.on && (pp.Cp != C || pp.nrp != nr);
+    pp.tmp_out = pp.on && pp.nqp != nq;
+    int base = dtype == ISPA_F32_SPLIT_ALWAYS ? ISPA_F32_SPLIT : dtype;
+    const size_t a = make_plan(base | inner_flags, B, pp.Cp, pp.nqp, pp.nrp, k).total;
+    const size_t b = make_plan(ISPA_F32 | inner_flags, B, pp.Cp, pp.nqp, pp.nrp, k).total;   // the plan a call may fall back to
+    pp.inner = align_up(a > b ? a : b, 256);
+    size_t off = pp.inner;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    pp.off_q = pp.copy_q ? take(elem * (size_t)B * pp.Cp * pp.nqp) : 0;
+    pp.off_r = pp.copy_r ? take(elem * (size_t)B * pp.Cp * pp.nrp) : 0;
+    pp.off_dist = pp.tmp_out ? take(sizeof(float) * (size_t)B * k * pp.nqp) : 0;
+    pp.off_idx = pp.tmp_out ? take(sizeof(int32_t) * (size_t)B * k * pp.nqp) : 0;
+    pp.total = off;
+    return pp;
+}
+
+// (B, C, n) -> (B, Cp, np): channels beyond C are zero, columns beyond n repeat column n - 1.  np is a multiple
+// of 8 and the output rows are 16-byte aligned: a thread builds 8 consecutive output cells (scalar loads: the
+// source rows are not aligned) and stores them as 16-byte vectors.
+template <typename T>
+__global__ __launch_bounds__(256) void nn_pad_map_kernel(const T *__restrict__ in, int C, int64_t n, T *__restrict__ out,
+                                                         int Cp, int64_t np) {
+    const int64_t j0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (j0 >= np) return;
+    T v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = T(0);
+    if (c < C) {
+        const T *row = in + ((int64_t)b * C + c) * n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[j0 + e < n ? j0 + e : n - 1];
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + ((int64_t)b * Cp + c) * np + j0);
+    const uint4 *src = reinterpret_cast<const uint4 *>(v);
+#pragma unroll
+    for (int e = 0; e < (int)(8 * sizeof(T) / 16); ++e) dst[e] = src[e];
+}
+// (rows, np) -> (rows, n): the results of the real query columns
+__global__ void nn_unpad_rows_kernel(const float *__restrict__ dist_p, const int32_t *__restrict__ idx_p, int64_t rows,
+                                     int64_t np, int64_t n, float *__restrict__ dist, int32_t *__restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = blockIdx.y;
+    if (j >= n) return;
+    dist[row * n + j] = dist_p[row * np + j];
+    idx[row * n + j] = idx_p[row * np + j];
+}
 }  // namespace
 
 extern "C" size_t ispa_nn_workspace_bytes_for(int dtype, int B, int C, int64_t nq, int64_t nr, int k) {
     if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
-    int base = dtype & ~ISPA_NN_NORMALIZE;
+    int base = dtype & ~(ISPA_NN_NORMALIZE | ISPA_NN_NO_PAD);
     const int flag = dtype & ISPA_NN_NORMALIZE;
-    if (base == ISPA_F32_SPLIT_ALWAYS) base = ISPA_F32_SPLIT;
-    if (base != ISPA_F32 && base != ISPA_BF16 && base != ISPA_F32_SPLIT) return 0;
+    if (base != ISPA_F32 && base != ISPA_BF16 && base != ISPA_F32_SPLIT && base != ISPA_F32_SPLIT_ALWAYS) return 0;
     if (flag && base == ISPA_BF16) return 0;
-    const size_t a = make_plan(base | flag, B, C, nq, nr, k).total;
-    const size_t b = make_plan(ISPA_F32 | flag, B, C, nq, nr, k).total;   // the plan a call may fall back to
-    return a > b ? a : b;
+    return make_pad_plan(dtype, B, C, nq, nr, k).total;
 }
 
 extern "C" size_t ispa_nn_workspace_bytes(int B, int C, int64_t nq, int64_t nr, int k) {
     if (B <= 0 || C <= 0 || nq <= 0 || nr <= 0 || k < 1 || k > kMaxK) return 0;
     // the larger of the two dtype plans, so that one workspace serves both
-    const size_t a = make_plan(ISPA_F32, B, C, nq, nr, k).total;
-    const size_t b = make_plan(ISPA_BF16, B, C, nq, nr, k).total;
+    const size_t a = make_pad_plan(ISPA_F32, B, C, nq, nr, k).total;
+    const size_t b = make_pad_plan(ISPA_BF16, B, C, nq, nr, k).total;
     return a > b ? a : b;
 }
 
@@ -523,22 +617,14 @@ extern "C" int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int 
 }
 
 namespace {
-int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr, int k,
-                    int index_base, float *dist, int32_t *idx, void *workspace, size_t workspace_bytes,
-                    int32_t *stats, void *stream, const char *workspace_name) {
-    ISPA_REQUIRE(B >= 0 && nq >= 0, "negative size");
-    ISPA_REQUIRE(k >= 1 && k <= kMaxK, "k = %d outside [1, %d]", k, kMaxK);
-    if (B == 0 || nq == 0) return ISPA_OK;
-    ISPA_REQUIRE(C >= 1 && nr >= 1, "need at least one channel and one reference (C=%d, nr=%lld)", C,
-                 (long long)nr);
-    ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31) && B <= 65535, "problem too large");
-    ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
+// One call on arrays the kernels can take as they are; reference cells [nr_valid, nr) are padding.
+int nn_topk_inner(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr, int64_t nr_valid,
+                  int k, int index_base, float *dist, int32_t *idx, void *workspace, size_t workspace_bytes,
+                  int32_t *stats, void *stream, const char *workspace_name) {
     const int flags = dtype & ISPA_NN_NORMALIZE;
     dtype &= ~ISPA_NN_NORMALIZE;
     const bool split_always = dtype == ISPA_F32_SPLIT_ALWAYS;
     if (split_always) dtype = ISPA_F32_SPLIT;
-    ISPA_REQUIRE(dtype == ISPA_F32 || dtype == ISPA_BF16 || dtype == ISPA_F32_SPLIT, "unknown dtype %d", dtype);
-    ISPA_REQUIRE(!(flags && dtype == ISPA_BF16), "ISPA_NN_NORMALIZE takes float32 features");
     Plan p = make_plan(dtype | flags, B, C, nq, nr, k);
     if (p.bf16_mfma && (((uintptr_t)q | (uintptr_t)r) % 16 != 0)) {
         p = make_plan(ISPA_F32, B, C, nq, nr, k);       // unaligned bf16 input: converting tile loader
@@ -556,12 +642,68 @@ int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64
     }
     if (workspace_bytes < p.total)
         return ispa::fail(ISPA_EWORKSPACE, "%s of %zu bytes given, %zu needed", workspace_name, workspace_bytes, p.total);
-    ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "%s must be 256-byte aligned", workspace_name);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ISPA_F32 || dtype == ISPA_F32_SPLIT)
-        return run((const float *)q, (const float *)r, B, C, nq, nr, k, index_base, dist, idx, (char *)workspace,
-                   p, stats, s);
-    return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, k, index_base, dist, idx,
+        return run((const float *)q, (const float *)r, B, C, nq, nr, nr_valid, k, index_base, dist, idx,
+                   (char *)workspace, p, stats, s);
+    return run((const uint16_t *)q, (const uint16_t *)r, B, C, nq, nr, nr_valid, k, index_base, dist, idx,
                (char *)workspace, p, stats, s);
+}
+
+int nn_topk_checked(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr, int k,
+                    int index_base, float *dist, int32_t *idx, void *workspace, size_t workspace_bytes,
+                    int32_t *stats, void *stream, const char *workspace_name) {
+    ISPA_REQUIRE(B >= 0 && nq >= 0, "negative size");
+    ISPA_REQUIRE(k >= 1 && k <= kMaxK, "k = %d outside [1, %d]", k, kMaxK);
+    if (B == 0 || nq == 0) return ISPA_OK;
+    ISPA_REQUIRE(C >= 1 && nr >= 1, "need at least one channel and one reference (C=%d, nr=%lld)", C,
+                 (long long)nr);
+    ISPA_REQUIRE(nr < (1ll << 30) && (int64_t)B * nq < (1ll << 31) && B <= 65535, "problem too large");
+    ISPA_REQUIRE(q && r && dist && idx && workspace, "null pointer");
+    const int base = dtype & ~(ISPA_NN_NORMALIZE | ISPA_NN_NO_PAD);
+    ISPA_REQUIRE(base == ISPA_F32 || base == ISPA_BF16 || base == ISPA_F32_SPLIT || base == ISPA_F32_SPLIT_ALWAYS,
+                 "unknown dtype %d", dtype);
+    ISPA_REQUIRE(!((dtype & ISPA_NN_NORMALIZE) && base == ISPA_BF16), "ISPA_NN_NORMALIZE takes float32 features");
+    ISPA_REQUIRE((uintptr_t)workspace % 256 == 0, "%s must be 256-byte aligned", workspace_name);
+    const PadPlan pp = make_pad_plan(dtype, B, C, nq, nr, k);
+    const int inner_dtype = dtype & ~ISPA_NN_NO_PAD;
+    if (!pp.on)
+        return nn_topk_inner(q, r, inner_dtype, B, C, nq, nr, nr, k, index_base, dist, idx, workspace, workspace_bytes,
+                             stats, stream, workspace_name);
+    if (workspace_bytes < pp.total)
+        return ispa::fail(ISPA_EWORKSPACE, "%s of %zu bytes given, %zu needed", workspace_name, workspace_bytes, pp.total);
+    ISPA_REQUIRE((int64_t)B * pp.nqp < (1ll << 31) && pp.Cp <= 65535, "problem too large");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const void *qi = q, *ri = r;
+    auto pad = [&](const void *in, int64_t n, void *out, int64_t np) {
+        const dim3 grid(ispa::blocks_for(np / 8, 256), pp.Cp, B);
+        if (base == ISPA_BF16)
+            hipLaunchKernelGGL((nn_pad_map_kernel<uint16_t>), grid, dim3(256), 0, s, (const uint16_t *)in, C, n,
+                               (uint16_t *)out, pp.Cp, np);
+        else
+            hipLaunchKernelGGL((nn_pad_map_kernel<float>), grid, dim3(256), 0, s, (const float *)in, C, n, (float *)out,
+                               pp.Cp, np);
+    };
+    if (pp.copy_q) {
+        pad(q, nq, ws + pp.off_q, pp.nqp);
+        qi = ws + pp.off_q;
+    }
+    if (pp.copy_r) {
+        pad(r, nr, ws + pp.off_r, pp.nrp);
+        ri = ws + pp.off_r;
+    }
+    if (int rc = ispa::check_launch("nn_pad_map_kernel")) return rc;
+    float *dist_i = pp.tmp_out ? (float *)(ws + pp.off_dist) : dist;
+    int32_t *idx_i = pp.tmp_out ? (int32_t *)(ws + pp.off_idx) : idx;
+    if (int rc = nn_topk_inner(qi, ri, inner_dtype, B, pp.Cp, pp.nqp, pp.nrp, nr, k, index_base, dist_i, idx_i, ws,
+                               pp.inner, stats, stream, workspace_name))
+        return rc;
+    if (pp.tmp_out) {
+        hipLaunchKernelGGL(nn_unpad_rows_kernel, dim3(ispa::blocks_for(nq, 256), (unsigned)(B * k)), dim3(256), 0, s,
+                           dist_i, idx_i, (int64_t)B * k, pp.nqp, nq, dist, idx);
+        if (int rc = ispa::check_launch("nn_unpad_rows_kernel")) return rc;
+    }
+    return ISPA_OK;
 }
 }  // namespace

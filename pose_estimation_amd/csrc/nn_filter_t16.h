@@ -236,8 +236,8 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
         __builtin_amdgcn_sched_barrier(0);
         half_step(rimg, 0, rimg, 1, a, init_a, acc_a, acc_b, chunk - 1, 1);
         if (wq_u == 0) nhbuf[next_slot * kBR + (tid & (kBR - 1))] = pre_ok ? pre_nh : kNegInf;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (ISPA_ABLATE != 7 && ISPA_ABLATE != 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ISPA_ABLATE != 8 && ISPA_ABLATE != 9) __syncthreads();
         if (ISPA_ABLATE != 2 && ISPA_ABLATE != 123) stage(clamp_chunk(chunk + 2), after_slot);
         if (wq_u == 0) fetch_nh(clamp_chunk(chunk + 2));
         init_a[0] = load_init(nhbuf + next_slot * kBR, 0, 0);

@@ -495,8 +495,8 @@ __device__ __forceinline__ void top2_insert(float x, int code, float &v0, int &c
 template <typename T>
 __global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
     const float *__restrict__ part_val, const int *__restrict__ part_idx, int nparts, const float *__restrict__ qnh,
-    int C, int64_t nq, int64_t nr, int index_base, float err_rel, float tag_rel, const T *__restrict__ q,
-    const T *__restrict__ r,
+    int C, int64_t nq, int64_t nr, int64_t nr_valid, int index_base, float err_rel, float tag_rel,
+    const T *__restrict__ q, const T *__restrict__ r,
     const double *__restrict__ qq64, const double *__restrict__ rr64, float *__restrict__ dist,
     int *__restrict__ idx, int *__restrict__ amb_count, int *__restrict__ amb_list, int *__restrict__ pair_count,
     int *__restrict__ pair_list, int *__restrict__ light_count) {
@@ -535,7 +535,8 @@ __global__ __launch_bounds__(64 * kFsWaves) void nn_finalize_small_kernel(
     }
     // largest squared reference norm of the pair, rounded up (what the norms pass gives the large-batch path)
     double m = 0.0;
-    for (int64_t j = tid; j < nr; j += 64 * kFsWaves) m = fmax(m, rr64[(int64_t)b * nr + j]);
+    // (cells from nr_valid on are padding: their norm entries are +inf)
+    for (int64_t j = tid; j < nr_valid; j += 64 * kFsWaves) m = fmax(m, rr64[(int64_t)b * nr + j]);
     float mf = __double2float_ru(m);
     for (int off = 32; off > 0; off >>= 1) mf = fmaxf(mf, __shfl_xor(mf, off));
     if (lane == 0) s_rmax[wave] = mf;

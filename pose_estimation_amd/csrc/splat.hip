@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             // positive ratio, plus a non-negative pad), so the conversions cannot overflow, the Python slice
             // [c - r : c + r] cannot wrap from above, and slice_anchor() reduces to: empty for c < r (the lower
             // bound wraps past the upper one), anchor c - r otherwise.  Lanes with ok == false carry garbage
-            // that is never used (the float -> int conversion saturates, it does not trap).
-            const int iu = (int)uc, iv = (int)vc;
+            // that is never used (cvt_i32_sat is defined for every input).
+            const int iu = cvt_i32_sat(uc), iv = cvt_i32_sat(vc);
             if (DILATE) {
                 ok = ok && iu >= spread && iv >= spread && iu < side + spread && iv < side + spread;
                 const int lr = iv - spread - (row0 - (w - 1));
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
             }
             // depth gate (pt2render.py:47-49) on the rounded coordinates as integers: u and v are integer-valued
             // (or not finite / huge, which saturate or become 0 and fail the gate like the float comparison)
-            const int gx = (int)u, gy = (int)v;
+            const int gx = cvt_i32_sat(u), gy = cvt_i32_sat(v);
             const bool gate = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
             const int64_t at = gate ? (int64_t)gy * W + gx : 0;
             cand[e] = ok && gate;
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
             double uc = u, vc = v;
             ok[e] = crop_apply(cx, tall, 1, uc, vc);
             // inside the crop the remapped coordinates lie in [0, kCropSide]: they fit 16 bits each
-            word[e] = ((int)vc << 16) | ((int)uc & 0xffff);
-            const int gx = (int)u, gy = (int)v;           // depth gate on the integer-valued pixel (pt2render.py:47-49)
+            word[e] = (cvt_i32_sat(vc) << 16) | (cvt_i32_sat(uc) & 0xffff);
+            const int gx = cvt_i32_sat(u), gy = cvt_i32_sat(v);   // depth gate on the integer-valued pixel (pt2render.py:47-49)
             gate[e] = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
             at[e] = gate[e] ? (int64_t)gy * W + gx : 0;
         }

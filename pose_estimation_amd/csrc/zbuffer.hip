@@ -190,8 +190,8 @@ __device__ __forceinline__ bool zb_pixel(const double (&a)[3], const double (&P)
     }
     // int() truncates; |trunc(u)| < 1e9 <=> |u| < 1e9; NaN fails every comparison
     const bool ok = fabs(u) < 1.0e9 && fabs(v) < 1.0e9 && z > 0.0 && z < __builtin_inf();
-    x = (int)u;
-    y = (int)v;
+    x = ispa_geom::cvt_i32_sat(u);                    // defined for the lanes that `ok` rejects, too
+    y = ispa_geom::cvt_i32_sat(v);
     return ok;
 }
 // depth alone (pass 2 on a cached pixel): the third row of the same fma chain
