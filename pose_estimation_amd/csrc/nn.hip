@@ -141,7 +141,7 @@ Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k)
 
 template <int KS, int KT>
 int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
-                int64_t nr, const Plan &p, float *pval, int *pidx) {
+                int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out, double *q64_out) {
     constexpr int lds_bytes = bf16_filter_lds_bytes<KS>();
     // more than 128 channels (one workgroup per CU): 8 waves of 32 queries where the chunk pieces divide evenly
     constexpr int QT = (KS > 8 && KS % 4 == 0) ? 1 : 2;
@@ -150,7 +150,7 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
                                          &configured))
         return rc;
     hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT, QT>), grid, dim3(512 / QT), lds_bytes, s, q, r, rnh, nq, nr,
-                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, qnh_out, q64_out);
     return ISPA_OK;
 }
 
@@ -159,7 +159,7 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
 #endif
 template <int KS32>
 int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
-               int64_t nr, const Plan &p, float *pval, int *pidx) {
+               int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out, double *q64_out) {
     constexpr int lds_bytes = bf16_filter_lds_bytes<2 * KS32>();
     // 4 waves of 64 queries; the 8-wave form (64 or 128 channels) is slower: 1.88 against 1.77 ms per 512 pairs
     constexpr int NQ = (KS32 % 2 == 0 && KS32 <= 4) ? ISPA_T16_NQ : 4;
@@ -168,7 +168,7 @@ int launch_t16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, c
                                          &configured))
         return rc;
     hipLaunchKernelGGL((nn_filter_bf16_t16_kernel<KS32, NQ>), grid, dim3(1024 / NQ), lds_bytes, s, q, r, rnh, nq, nr,
-                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx);
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, qnh_out, q64_out);
     return ISPA_OK;
 }
 
@@ -188,16 +188,16 @@ int launch_split(dim3 grid, hipStream_t s, const uint16_t *qhi, const uint16_t *
 
 template <int KT>
 int launch_bf16_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh,
-                   int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx) {
+                   int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out, double *q64_out) {
     switch (ks) {
-        case 2: return launch_bf16<2, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 4: return launch_bf16<4, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 6: return launch_bf16<6, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 8: return launch_bf16<8, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 10: return launch_bf16<10, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 12: return launch_bf16<12, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        case 14: return launch_bf16<14, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
-        default: return launch_bf16<16, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx);
+        case 2: return launch_bf16<2, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 4: return launch_bf16<4, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 6: return launch_bf16<6, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 8: return launch_bf16<8, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 10: return launch_bf16<10, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 12: return launch_bf16<12, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 14: return launch_bf16<14, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        default: return launch_bf16<16, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
     }
 }
 
@@ -237,6 +237,13 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr
     if (!small) ISPA_HIP(hipMemsetAsync(ws + p.off_rmax, 0, p.off_list - p.off_rmax, s));
     uint16_t *qhi = (uint16_t *)(ws + p.off_qhi), *qlo = (uint16_t *)(ws + p.off_qlo);
     uint16_t *rhi = (uint16_t *)(ws + p.off_rhi), *rlo = (uint16_t *)(ws + p.off_rlo);
+    // The bfloat16 MFMA filters stage their query tile through LDS and compute the query norms there (first needed by
+    // the finalize pass): the norms pass then reads the reference map only.
+    const bool filter_qnorms = p.bf16_mfma && !small;
+    float *fq_nh = filter_qnorms ? qnh : nullptr;
+    double *fq_64 = filter_qnorms ? q64 : nullptr;
+    (void)fq_nh;
+    (void)fq_64;
     bool norms_done = false;
     if (p.normalize && sizeof(T) == 4) {
         // L2-normalised copies of both maps + their norms in one sweep; everything below reads the copies
@@ -263,7 +270,14 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr
     } else {
         // workspace blocks are 256-byte aligned, so nh / sq64 rows are aligned whenever n % 4 == 0
         const bool q4 = nq % 4 == 0 && (uintptr_t)q % 16 == 0, r4 = nr % 4 == 0 && (uintptr_t)r % 16 == 0;
-        if (q4 && r4) {
+        if (filter_qnorms) {
+            if (r4)
+                hipLaunchKernelGGL((nn_norms4_kernel<T>), dim3(ispa::blocks_for(nr / 4, 256), B), dim3(256), 0, s, r, C,
+                                   nr, rnh, r64, rmax);
+            else
+                hipLaunchKernelGGL((nn_norms_kernel<T>), dim3(ispa::blocks_for(nr, 256), B), dim3(256), 0, s, r, C, nr,
+                                   rnh, r64, rmax);
+        } else if (q4 && r4) {
             const unsigned nbq = ispa::blocks_for(nq / 4, 256), nbr = ispa::blocks_for(nr / 4, 256);
             hipLaunchKernelGGL((nn_norms4_both_kernel<T>), dim3(nbq + nbr, B), dim3(256), 0, s, q, r, C, nq, nr,
                                (int)nbq, qnh, q64, rnh, r64, rmax);
@@ -326,21 +340,21 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr
         int rc;
         if (p.t16) {
             switch (C / 32) {
-                case 1: rc = launch_t16<1>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 2: rc = launch_t16<2>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 3: rc = launch_t16<3>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 4: rc = launch_t16<4>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 5: rc = launch_t16<5>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 6: rc = launch_t16<6>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                case 7: rc = launch_t16<7>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
-                default: rc = launch_t16<8>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx); break;
+                case 1: rc = launch_t16<1>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 2: rc = launch_t16<2>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 3: rc = launch_t16<3>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 4: rc = launch_t16<4>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 5: rc = launch_t16<5>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 6: rc = launch_t16<6>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                case 7: rc = launch_t16<7>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
+                default: rc = launch_t16<8>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
             }
         }
 #if ISPA_TOP1_32X32
-        else if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        else if (p.ktemplate == 1) rc = launch_bf16_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
 #endif
-        else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
-        else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx);
+        else if (p.ktemplate == 5) rc = launch_bf16_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
+        else rc = launch_bf16_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
         if (rc) return rc;
     } else {
         // v_mfma_f32_32x32x2_f32 is a k-ordered float32 fma chain: C+1 roundings of at most

@@ -83,6 +83,29 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *lds_row0_col, int stride) 
     return u.v;
 }
 
+// The query norms, from the block's query image in LDS (C rows of `tile` bfloat16 cells, zero beyond the map's
+// end): -|q|^2 / 2 as float32 and |q|^2 as float64, the sum in increasing channel order in float64 - bit for bit
+// what nn_norms_kernel computes from the map.  The filter kernels that stage their queries through LDS do this
+// on the way (the blocks of reference split 0 write), which saves the norms pass a whole read of the query map.
+template <int C, int NT>
+__device__ __forceinline__ void query_norms_from_image(const char *image, int stride, int tile, int64_t q0, int64_t nq,
+                                                       int b, int split, float *__restrict__ qnh_out,
+                                                       double *__restrict__ q64_out) {
+    if (qnh_out == nullptr || split != 0) return;       // uniform
+    for (int col = threadIdx.x; col < tile; col += NT) {
+        double s = 0.0;
+#pragma unroll 16
+        for (int c = 0; c < C; ++c) {
+            const float v = load_as_float(reinterpret_cast<const uint16_t *>(image + c * stride) + col);
+            s = fma((double)v, (double)v, s);
+        }
+        if (q0 + col < nq) {
+            qnh_out[(int64_t)b * nq + q0 + col] = (float)(-0.5 * s);
+            q64_out[(int64_t)b * nq + q0 + col] = s;
+        }
+    }
+}
+
 template <int KS>
 constexpr int bf16_filter_lds_bytes() {
     constexpr int stream = 3 * 16 * KS * kRStride + 3 * kBR * (int)sizeof(float);
@@ -98,7 +121,7 @@ template <int KS, int K, int QT>
 __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filter_bf16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
-    int *__restrict__ part_idx) {
+    int *__restrict__ part_idx, float *__restrict__ qnh_out, double *__restrict__ q64_out) {
     constexpr int C = 16 * KS;
     constexpr int kRBuf = C * kRStride;                 // one reference chunk image
     constexpr int kNT = 512 / QT;                       // threads
@@ -192,6 +215,7 @@ __global__ __launch_bounds__(512 / QT, (KS > 8 || QT == 1) ? 1 : 2) void nn_filt
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             bq[qi][ks] = tr_frag(lds + (ks * 16 + tr_row) * kQStride + (wq * 32 * QT + qi * 32 + tr_col) * 2, kQStride);
+    query_norms_from_image<C, kNT>(lds, kQStride, kBQ, q0, nq, b, split, qnh_out, q64_out);
     __syncthreads();                                     // query image no longer needed
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);

@@ -28,7 +28,7 @@ template <int KS32, int NQ>
 __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf16_t16_kernel(
     const uint16_t *__restrict__ q, const uint16_t *__restrict__ r, const float *__restrict__ rnh, int64_t nq,
     int64_t nr, int n_qtiles, int nsplit, int64_t refs_per_split, float *__restrict__ part_val,
-    int *__restrict__ part_idx) {
+    int *__restrict__ part_idx, float *__restrict__ qnh_out, double *__restrict__ q64_out) {
     constexpr int C = 32 * KS32;
     constexpr int KS = 2 * KS32;                        // 16-channel units, as in bf16_filter_lds_bytes
     constexpr int kRBuf = C * kRStride;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(1024 / NQ, KS32 > 4 ? 1 : 8 / NQ) void nn_filter_bf
 #pragma unroll
         for (int ks = 0; ks < KS32; ++ks)
             bq[qt][ks] = tr_frag(lds + (ks * 32 + tr_row) * kQStride + (wq * 16 * NQ + qt * 16 + tr_col) * 2, kQStride);
+    query_norms_from_image<C, kNT>(lds, kQStride, kBQ, q0, nq, b, split, qnh_out, q64_out);
     __syncthreads();
     if (nchunks > 0) {
         stage(clamp_chunk(0), 0);
