@@ -419,8 +419,8 @@ def run_geometry(args, torch, dist, world, rank, dev):
          "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_tile_kernel",
          "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel",
          "make_disparity_ws": "disparity_points_kernel+disparity_bands_kernel"}[names[dom]],
-        args.workload == "corr" or (n == 100000 and (args.poses == 3600 if args.workload in ("project", "zbuffer")
-                                                      else args.maps == 256)))
+        args.workload == "corr" or (n == 100000 and not sharded and
+                                    (args.poses == 3600 if args.workload in ("project", "zbuffer") else args.maps == 256)))
     if getattr(args, "depth_per_pose", False):
         traffic, traffic_src = None, None                # the committed counter passes ran with one shared depth map
     if traffic:
