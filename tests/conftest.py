@@ -70,6 +70,26 @@ def crosspin_cases(z, tag, k):
                np.ascontiguousarray(top[i, :, :k].T + 1), decided)
 
 
+def physical_zbuffer_case():
+    """(surface samples (n, 3) of the reference's shipped bed mesh, pose, Blender's depth render of that mesh, the
+    agreement measured when the fixture was made): see tests/golden/make_golden.py gen_zbuffer_physical."""
+    import json
+    from pose_estimation_amd import run_proj
+    mesh = np.load(os.path.join(GOLDEN, "bed_mesh.npz"))
+    with open(os.path.join(GOLDEN, "zbuffer_physical.json")) as fh:
+        stats = json.load(fh)
+    pts = run_proj.sample_surface(mesh["vertices"], mesh["faces"], stats["samples"], seed=stats["sample_seed"])
+    shipped = np.load(os.path.join(GOLDEN, "demo_flow.npz"))["shipped_depth"]
+    return pts, stats["pose"], shipped, stats
+
+
+def physical_zbuffer_agreement(depth, shipped):
+    cov, mask = np.isfinite(depth), shipped < 10.0        # Blender's depth pass is clamped to 10 behind the object
+    both = cov & mask
+    d = np.abs(depth[both] - shipped[both])
+    return both.sum() / (cov | mask).sum(), float(np.median(d)), float((d < 0.01).mean())
+
+
 @pytest.fixture(scope="session")
 def golden_tables():
     import json

@@ -633,6 +633,21 @@ def test_zbuffer_config4_pose_sweep(pea):
         assert 20000 < int(vis.sum()) < 100000
 
 
+def test_project_zbuffer_against_the_blender_render(pea):
+    """The fused z-buffer against the one physical depth measurement the reference ships: Blender's render of its
+    bed mesh (see test_zbuffer_oracle_against_the_blender_render for what is compared and how approximate it is),
+    and bit for bit against the oracle on the same 800k samples."""
+    from conftest import physical_zbuffer_agreement, physical_zbuffer_case
+    pts, pose, shipped, stats = physical_zbuffer_case()
+    pts = pts[pea.run_proj.spatial_order(pts)]
+    cam = pea.pt2render.camera_matrices(np.array([pose]))
+    got = pea.zbuffer.project_zbuffer(pts, cam, (540, 960), radius=0, relax=0.01, want=("packed", "depth", "truth"))
+    iou, med, near = physical_zbuffer_agreement(got["depth"][0], shipped)
+    assert iou > 0.97 and med < 0.003 and near > 0.88, (iou, med, near)
+    render, key, win, depth, vis = _zb_oracle(pts, cam[0], 540, 960, 0, 0.01)
+    assert np.array_equal(got["packed"][0].view(np.uint64), key) and np.array_equal(got["truth"][0], vis)
+
+
 @pytest.mark.parametrize("n,radius", [(100000, 0), (100000, 2), (150000, 0), (150000, 1)])
 def test_project_zbuffer_unsorted_large_models(pea, n, radius):
     """Points in the reference's own (random) sampling order: every chunk of 64 consecutive points spans the whole
