@@ -18,6 +18,12 @@
  *     pairs, maps or poses are independent; the exchange of result records between ranks is the
  *     caller's (the Python layer uses torch.distributed all_gather_into_tensor over RCCL), because the
  *     process that owns the ranks also owns their bootstrap and stream ordering;
+ *   - threads: one host thread per GPU at a time.  Calls from several host threads on ONE GPU are not
+ *     supported: the library keeps per-process state that is set on first use without locks (per-kernel
+ *     launch attributes, the timing hooks' event slots, the scratch array of ispa_nn_topk_noalloc), and two
+ *     calls that share a workspace race on the device.  Calls on different GPUs from different threads are
+ *     fine once each GPU has made its first call of a given kind; the intended deployment is one process
+ *     per GPU;
  *   - arrays are C-ordered; "pt_render" always means the reference's (3, N) float64 layout with
  *     rows [u, v, z] (pt2render.py:6-13), batched as (n_pose, 3, N).
  */
@@ -188,9 +194,10 @@ int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n, int n_pos
  * ispa_project -> ispa_zbuffer -> ispa_zbuffer_visibility_packed:
  *   packed (n_pose,H,W) u64 keys, winner (n_pose,H,W) int32, depth (n_pose,H,W) f32, truth (n_pose,n) u8.
  * workspace: ispa_project_zbuffer_workspace_bytes(n, n_pose, H, W) bytes, 256-byte aligned (bounding boxes
- * of chunks of 256 consecutive points per pose).  Results do not depend on the order of the points; speed
- * does: with the model's points in a spatially coherent order (e.g. Morton order, once per model) a tile
- * visits only the chunks that project near it, with points in random order every tile visits every chunk. */
+ * of chunks of 64 consecutive points per pose).  Results do not depend on the order of the points; speed
+ * does: with the model's points in a spatially coherent order (e.g. along a Hilbert curve, once per model:
+ * run_proj.spatial_order in the Python layer) a tile visits only the chunks that project near it, with
+ * points in random order every tile visits every chunk. */
 size_t ispa_project_zbuffer_workspace_bytes(int64_t n, int n_pose, int H, int W);
 int ispa_project_zbuffer(const double *pts, int64_t n, const double *cams, int n_pose, int H, int W,
                          int radius, double relax, uint64_t *packed, int32_t *winner, float *depth,
@@ -237,7 +244,11 @@ int ispa_nn_topk(const void *q, const void *r, int dtype, int B, int C, int64_t 
  * process ends.  The call allocates and frees nothing.  Problems whose ispa_nn_workspace_bytes_for() exceeds
  * the array are rejected with ISPA_EWORKSPACE (one 64x64x128 pair needs 4 to 8 MiB, the three 128x128x256 top-5
  * views of one multi-view query 38 MiB).  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
- * (two streams, two host threads) race; calls on one stream are ordered and safe. */
+ * (two streams, two host threads) race; calls on one stream are ordered and safe.
+ * Under stream capture: the FIRST call on a device looks up the array's address (hipGetSymbolAddress) and the
+ * first call of each kernel variant (dtype, channel count, k) raises that kernel's dynamic-LDS limit
+ * (hipFuncSetAttribute); neither is a stream operation, so make one un-captured call with the same dtype, C and k
+ * on the device before capturing.  Every later call only enqueues kernels and memsets on `stream`. */
 #define ISPA_NN_NOALLOC_SCRATCH_BYTES (64u << 20)
 size_t ispa_nn_noalloc_scratch_bytes(void);
 int ispa_nn_topk_noalloc(const void *q, const void *r, int dtype, int B, int C, int64_t nq, int64_t nr,

@@ -68,3 +68,42 @@ def test_nn_topk_noalloc_matches_the_workspace_entry_point():
     rc = _abi.lib.ispa_nn_topk_noalloc(big_q.data_ptr(), big_q.data_ptr(), _abi.F32, 1, 128, 4096, 4096, 9, 1,
                                        big_q.data_ptr(), big_q.data_ptr(), None, None)
     assert rc == -1
+
+
+def test_nn_topk_noalloc_under_graph_capture():
+    """One warm call outside capture (it looks up the scratch address and sets the kernels' launch attributes), then
+    the call is captured into a HIP graph and replayed on new inputs: same bits as the eager call."""
+    import torch
+    from pose_estimation_amd import _abi
+    g = torch.Generator(device="cuda").manual_seed(78)
+
+    def unit(*shape):
+        x = torch.randn(*shape, device="cuda", generator=g)
+        return (x / x.norm(dim=1, keepdim=True)).contiguous()
+    b, c, nq, nr, k = 2, 128, 1024, 2048, 1
+    q, r = unit(b, c, nq), unit(b, c, nr)
+    d = torch.empty((b, k, nq), dtype=torch.float32, device="cuda")
+    i = torch.empty((b, k, nq), dtype=torch.int32, device="cuda")
+
+    def call():
+        _abi.check(_abi.lib.ispa_nn_topk_noalloc(q.data_ptr(), r.data_ptr(), _abi.F32, b, c, nq, nr, k, 1,
+                                                 d.data_ptr(), i.data_ptr(), None,
+                                                 torch.cuda.current_stream().cuda_stream))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()                                            # warm, un-captured
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for _ in range(2):
+        q.copy_(unit(b, c, nq))
+        r.copy_(unit(b, c, nr))
+        graph.replay()
+        torch.cuda.synchronize()
+        d_g, i_g = d.clone(), i.clone()
+        call()                                            # eager, same inputs
+        torch.cuda.synchronize()
+        assert torch.equal(i_g, i) and torch.equal(d_g.view(torch.int32), d.view(torch.int32))
