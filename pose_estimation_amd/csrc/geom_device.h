@@ -108,17 +108,32 @@ __device__ __forceinline__ int cvt_i32_sat(double x) {
 // two Newton steps gives the quotient to a few ulp, which rounds to the same integer as the
 // correctly rounded quotient unless it lies within 1e-5 of a half-integer (or is huge / not
 // finite); only those lanes take the exact division.  Bit-identical to rint(a / b) by construction.
-__device__ __forceinline__ double rint_div(double a, double b) {
+__device__ __forceinline__ double refined_rcp(double b) {
     double r = __builtin_amdgcn_rcp(b);
     double e = fma(-b, r, 1.0);
     r = fma(r, e, r);
     e = fma(-b, r, 1.0);
-    r = fma(r, e, r);
-    const double y = a * r;
+    return fma(r, e, r);
+}
+__device__ __forceinline__ double rint_div(double a, double b) {
+    const double y = a * refined_rcp(b);
     double n = rint(y);
     const bool safe = fabs(y) < 1.0e9 && fabs(y - n) < 0.5 - 1.0e-5;
     if (__builtin_expect(!safe, 0)) n = rint(a / b);
     return n;
+}
+// Two quotients over one denominator (the two pixel coordinates of a projected point): one reciprocal, one
+// branch for the lanes that need an exact division.
+__device__ __forceinline__ void rint_div2(double a0, double a1, double b, double &n0, double &n1) {
+    const double r = refined_rcp(b);
+    const double y0 = a0 * r, y1 = a1 * r;
+    n0 = rint(y0);
+    n1 = rint(y1);
+    const bool safe = fabs(y0) < 1.0e9 && fabs(y0 - n0) < 0.5 - 1.0e-5 && fabs(y1) < 1.0e9 && fabs(y1 - n1) < 0.5 - 1.0e-5;
+    if (__builtin_expect(!safe, 0)) {
+        n0 = rint(a0 / b);
+        n1 = rint(a1 / b);
+    }
 }
 
 __device__ __forceinline__ void project_point(const double *__restrict__ P, double px, double py,
@@ -133,8 +148,7 @@ __device__ __forceinline__ void project_point(const double *__restrict__ P, doub
         a[r] = acc;
     }
     z = a[2];
-    u = rint_div(a[0], a[2]);
-    v = rint_div(a[1], a[2]);
+    rint_div2(a[0], a[1], a[2], u, v);
 }
 
 }  // namespace ispa_geom
