@@ -414,15 +414,13 @@ def run_geometry(args, torch, dist, world, rank, dev):
         roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_PEAK_TFLOPS["f32"], 4)}
     traffic, traffic_src = measured_traffic(
-        args.workload + ("_unfused" if args.unfused else ""),
+        args.workload + ("_unfused" if args.unfused else "") + ("_depth_per_pose" if getattr(args, "depth_per_pose", False) else ""),
         {"project_prune": "project_prune2_kernel", "flow_band": "flow_band_kernel", "project": "project2_kernel",
          "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_tile_kernel",
          "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel",
          "make_disparity_ws": "disparity_points_kernel+disparity_bands_kernel"}[names[dom]],
         args.workload == "corr" or (n == 100000 and not sharded and
                                     (args.poses == 3600 if args.workload in ("project", "zbuffer") else args.maps == 256)))
-    if getattr(args, "depth_per_pose", False):
-        traffic, traffic_src = None, None                # the committed counter passes ran with one shared depth map
     if traffic:
         # the profile's counter bytes over THIS run's kernel time: the rate HBM really delivered
         roof["hbm_frac_counter"] = round(traffic / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
