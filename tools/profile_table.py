@@ -1,9 +1,9 @@
-"""Markdown table of the committed rocprofv3 evidence of one round, for DESIGN.md:
+"""Markdown table of the committed rocprofv3 evidence of one profiling pass (file prefix, e.g. r03):
     python tools/profile_table.py profiles r03
 Per profiled bench command: the bench line of the traced run (value, step time, kernel time by HIP events), the
 traced average of the dominant kernel, the algorithmic work per launch and the roofline fraction it gives with the
 TRACED duration, and the HBM bytes of the counter passes.  Profiled runs are a few per cent slower than plain ones
-(the default bench line of the same tree is <round>_bench_default.json)."""
+(the default bench line of the same tree is <prefix>_bench_default.json)."""
 import csv
 import glob
 import json
