@@ -704,6 +704,24 @@ def main():
 
     default_shape = (b, g, c, args.k, args.dtype, filt) == (512, 64, 128, 1, "f32", "native") and not args.matches
     if world == 1 and default_shape and not args.no_extra:
+        # BASELINE config 2 literally: ONE 64x64x128 float32 pair per call (a latency case: a chain of five short
+        # dependent launches), pipelined on one stream and with a host wait after every call
+        q1, r1 = q[:1].contiguous(), r[:1].contiguous()
+        el1, k1 = side_run(lambda: pea.correspondence.dense_nn(q1, r1, 1), 200)
+        for _ in range(20):
+            pea.correspondence.dense_nn(q1, r1, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            pea.correspondence.dense_nn(q1, r1, 1)
+            torch.cuda.synchronize()
+        waited = (time.perf_counter() - t0) / 200
+        extra["single_pair_f32"] = {
+            "value": round(200 / el1, 1), "unit": "pairs/s", "calls": 200, "us_per_call_pipelined": round(el1 / 200 * 1e6, 1),
+            "us_per_call_waited": round(waited * 1e6, 1), "filter_kernel_us": round(k1 * 1e3, 1),
+            "filter_tflops": round(2.0 * n * n * c / (k1 * 1e-3) / 1e12, 1),
+            "workload": f"one {g}x{g}x{c} float32 pair per call (BASELINE config 2)"}
+        del q1, r1
         # The metric names correspondence AND disparity maps: per image pair one dense NN correspondence and one
         # make_disparity flow map (100k-point model) in the same timed region, back to back on one stream.
         disp, keep = disparity_step(torch, dev, b, 100000, "chair", 300)
