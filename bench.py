@@ -385,7 +385,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
             # fused: points read once per map, one depth gather per point, the flow map written
             alg_bytes = [(24.0 * n + 4.0 * n + 802816.0) * M]
             names = ["make_disparity" if args.one_launch else "make_disparity_ws"]
-            workload = (f"make_disparity flow maps, fused ({'one launch' if args.one_launch else 'two launches, 4 B of workspace per point and map'}): "
+            workload = (f"make_disparity flow maps, fused ({'one launch' if args.one_launch else 'two launches, 16 B of workspace per point and map'}): "
                         f"{M} renders per GPU per step of a {n}-point "
                         f"model (projection at 2 poses, depth visibility, crop, 224x224x2 float64 flow splat)")
     for _ in range(args.warmup):

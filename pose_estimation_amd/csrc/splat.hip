@@ -320,19 +320,30 @@ __global__ __launch_bounds__(kBandThreads) void make_disparity_kernel(
     }
 }
 
-// make_disparity in two launches, for callers that bring a workspace of 4 bytes per (map, point).
+// make_disparity in two launches, for callers that bring a workspace.
 // make_disparity_kernel above is bound by vector instructions, and spends most of them twice: each of a map's two
 // half-map bands projects every point.  Here the per-point part runs once per (map, point), in a launch with as
-// many waves as the chip holds, and leaves one word per point: (remapped v << 16) | remapped u of a point that is
-// inside the crop and visible at pose 1, -1 otherwise; the band blocks then only read those words.
+// many waves as the chip holds; a point that is inside the crop and visible at pose 1 becomes the record
+// (remapped v << 16) | remapped u, and the band blocks only read records.
 #ifndef DISP_PPT
 #define DISP_PPT 4
 #endif
 constexpr int kPointsPerThread = DISP_PPT;    // per map: amortises the crop transform (two float64 divisions)
+// The kernel leaves per (map, band) a COMPACT list of the kept points that can write into that band: (record, tag)
+// pairs with tag = rank + 1 (the point's index in the reference's order; the
+// position + 1 without ranks).  A workgroup reserves room for its entries with one atomic per band on the list's
+// length (zeroed by the caller of the kernel), so a list is contiguous and in no particular order -- the owner of
+// a pixel is a maximum, which does not depend on it.  The band blocks then read a few hundred KB of entries per
+// map instead of scanning every point's record (and rank) once per band.
+constexpr int kDispBandRows = kBandPixels / (int)ispa_geom::kCropSide;
+constexpr int kDispBands = ((int)ispa_geom::kCropSide + kDispBandRows - 1) / kDispBandRows;
+constexpr int kResolveChunk = 4;             // x 64 pixels per wave between two queue drains
+constexpr size_t kResolveQueueBytes = (size_t)kBandThreads * kResolveChunk * sizeof(int2) + 8;
 __global__ __launch_bounds__(256) void disparity_points_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const float *__restrict__ depth,
     int depth_per_map, int H, int W, int ylim, int xlim, double relax, const int32_t *__restrict__ crop,
-    int crop_per_map, int n_map, int nbx, int32_t *__restrict__ rec) {
+    int crop_per_map, int n_map, int nbx, const int32_t *__restrict__ rank, int spread, int2 *__restrict__ lists,
+    int32_t *__restrict__ counts) {
     using namespace ispa_geom;
     // 1-D grid; workgroups b and b + 8 run on the same XCD.  All point blocks of a map go to one XCD and follow
     // each other there, so that the depth texels the map's points gather (a few hundred KB around the object)
@@ -340,26 +351,30 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
     const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
     const int m = (wq / nbx) * 8 + xcd;
     if (m >= n_map) return;
+    __shared__ int s_cnt[kDispBands][4], s_base[kDispBands];
     const double *P1 = cams1 + 12 * (int64_t)m;
     const float *d = depth + (depth_per_map ? (int64_t)m * H * W : 0);
     const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
     const CropXform cx = make_crop(c);
     const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
-    int32_t *out = rec + (int64_t)m * n;
-    const int64_t base = (int64_t)(wq % nbx) * 256 * kPointsPerThread + threadIdx.x;
+    const int blk = wq % nbx;
+    const int64_t base = (int64_t)blk * (256 * kPointsPerThread) + threadIdx.x;
     constexpr int kBatch = 4;                     // loads, then gathers, of four points in flight together
-    for (int e0 = 0; e0 < kPointsPerThread; e0 += kBatch) {
+    static_assert(kPointsPerThread == kBatch, "one batch per thread: the compaction below indexes it by e");
+    int word[kBatch], tag[kBatch];
+    {
         double px[kBatch], py[kBatch], pz[kBatch];
+        int rk[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)(e0 + e) * 256;
+            const int64_t i = base + (int64_t)e * 256;
             const int64_t j = i < n ? i : 0;
             px[e] = pts[3 * j];
             py[e] = pts[3 * j + 1];
             pz[e] = pts[3 * j + 2];
+            rk[e] = rank ? rank[j] : (int)j;
         }
         bool ok[kBatch], gate[kBatch];
-        int word[kBatch];
         int64_t at[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
@@ -379,12 +394,59 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
         for (int e = 0; e < kBatch; ++e) texel[e] = d[at[e]];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)(e0 + e) * 256;
-            if (i < n) out[i] = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax) ? word[e] : -1;
+            const int64_t i = base + (int64_t)e * 256;
+            const bool keep = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax);
+            // a rank outside [0, n) drops its point (it can never own a pixel)
+            const bool listed = keep && i < n && (unsigned)rk[e] < (unsigned)n;
+            tag[e] = rk[e] + 1;
+            word[e] = listed ? word[e] : -1;
+        }
+    }
+    // ---- compaction: per band, this workgroup's kept points that can reach the band's rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long mask[kDispBands][kBatch];
+#pragma unroll
+    for (int bnd = 0; bnd < kDispBands; ++bnd) {
+        const int row0 = bnd * kDispBandRows, row1 = min(row0 + kDispBandRows, (int)kCropSide);
+        int total = 0;
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int iv = word[e] >> 16;
+            // the rows a point writes lie in [iv - spread, iv + spread)
+            const bool in = word[e] >= 0 && iv + spread >= row0 && iv - spread < row1;
+            mask[bnd][e] = __builtin_amdgcn_ballot_w64(in);
+            total += __popcll(mask[bnd][e]);
+        }
+        if (lane == 0) s_cnt[bnd][wave] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x < kDispBands) {
+        const int bnd = threadIdx.x;
+        const int all = s_cnt[bnd][0] + s_cnt[bnd][1] + s_cnt[bnd][2] + s_cnt[bnd][3];
+        s_base[bnd] = all ? atomicAdd(&counts[m * kDispBands + bnd], all) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bnd = 0; bnd < kDispBands; ++bnd) {
+        int at = s_base[bnd];
+#pragma unroll
+        for (int w2 = 0; w2 < 3; ++w2) at += w2 < wave ? s_cnt[bnd][w2] : 0;
+        int2 *dst = lists + ((int64_t)m * kDispBands + bnd) * n;
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            if ((mask[bnd][e] >> lane) & 1ull) dst[at + __popcll(mask[bnd][e] & below)] = make_int2(word[e], tag[e]);
+            at += __popcll(mask[bnd][e]);
         }
     }
 }
 
+#ifdef DISP_STAMP
+__device__ unsigned long long g_stamp[8];
+#define STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_stamp[k], t_ - t0_); t0_ = t_; } } while (0)
+#else
+#define STAMP(k)
+#endif
 // ORDERED: the points arrive in a processing order of the caller's choice (e.g. along a space-filling curve, so
 // that the points kernel's depth gathers coalesce) and rank[i] is point i's index in the reference's order: the
 // kept point with the highest RANK wins a pixel, and inverse[rank] finds it again for the flow value.  Ranks
@@ -392,83 +454,145 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
 template <bool DILATE, bool ORDERED>
 __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
-    const int32_t *__restrict__ rec, const int32_t *__restrict__ crop, int crop_per_map, int spread, int band_rows,
-    double *__restrict__ flow, const int32_t *__restrict__ rank, const int32_t *__restrict__ inverse) {
+    const int32_t *__restrict__ crop, int crop_per_map, int spread, double *__restrict__ flow,
+    const int2 *__restrict__ lists, const int32_t *__restrict__ counts, const int32_t *__restrict__ inverse) {
     using namespace ispa_geom;
     extern __shared__ int owner[];
     constexpr int side = (int)kCropSide;
     const int m = blockIdx.y;
-    const int row0 = blockIdx.x * band_rows;
-    const int row1 = min(row0 + band_rows, side);
+    const int row0 = blockIdx.x * kDispBandRows;
+    const int row1 = min(row0 + kDispBandRows, side);
     const int npix = (row1 - row0) * side;
     const int w = 2 * spread, pw = side + w - 1;         // DILATE: anchor image (band rows + w - 1) x pw
     const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
+    const int2 *lst = lists + ((int64_t)m * kDispBands + blockIdx.x) * n;
+    // Two batches of entries per thread travel while the image is cleared, and they are asked for before the
+    // list's length is known (a list has room for n entries, so the read is in bounds; what lies beyond the
+    // length is dropped below): the length and the entries arrive together instead of one after the other.
+    constexpr int kBatch = 8;
+    int2 ent[2][kBatch];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int f = (h * kBatch + e) * kBandThreads + threadIdx.x;
+            ent[h][e] = lst[f < n ? f : 0];
+        }
+    const int total = min(counts[m * kDispBands + blockIdx.x], (int)n);
+#ifdef DISP_STAMP
+    unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
     for (int p = threadIdx.x; p < nimg; p += kBandThreads) owner[p] = 0;
     __syncthreads();
-    const int32_t *rm = rec + (int64_t)m * n;
-    constexpr int kBatch = 8;
-    for (int64_t base = 0; base < n; base += (int64_t)kBandThreads * kBatch) {
-        int r[kBatch], rk[kBatch];
-#pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
-            r[e] = rm[i < n ? i : 0];
-            rk[e] = ORDERED ? rank[i < n ? i : 0] : (int)i;
+    STAMP(0);
+    auto splat = [&](const int2 en, int f) {
+        if (f >= total || en.x < 0) return;
+        const int iu = en.x & 0xffff, iv = en.x >> 16;
+        const int tag = en.y;
+        if (DILATE) {
+            // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
+            // below the spread and anchored at c - spread otherwise
+            if (iu < spread || iv < spread || iu >= side + spread || iv >= side + spread) return;
+            const int lr = iv - spread - (row0 - (w - 1)), lc = iu - spread + w - 1;
+            if (lr < 0 || iv - spread >= row1) return;
+            // the anchor's own position (mod 8) rides in the low bits: the pixel that finds this value as
+            // its window maximum knows which of its w x w anchors it came from, i.e. the owner's pixel
+            atomicMax(&owner[lr * pw + lc], (tag << 6) | ((lr & 7) << 3) | (lc & 7));
+        } else {
+            int y0, y1, x0, x1;
+            py_slice(iv, spread, side, y0, y1);
+            y0 = max(y0, row0);
+            y1 = min(y1, row1);
+            if (y0 >= y1) return;
+            py_slice(iu, spread, side, x0, x1);
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
         }
+    };
+    for (int base = 0; base < total; base += 2 * kBandThreads * kBatch) {
 #pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)e * kBandThreads + threadIdx.x;
-            if (i >= n || r[e] < 0) continue;
-            if (ORDERED && (unsigned)rk[e] >= (unsigned)n) continue;
-            const int iu = r[e] & 0xffff, iv = r[e] >> 16;
-            const int tag = rk[e] + 1;
-            if (DILATE) {
-                // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
-                // below the spread and anchored at c - spread otherwise
-                if (iu < spread || iv < spread || iu >= side + spread || iv >= side + spread) continue;
-                const int lr = iv - spread - (row0 - (w - 1));
-                if (lr < 0 || iv - spread >= row1) continue;
-                atomicMax(&owner[lr * pw + iu - spread + w - 1], tag);
-            } else {
-                int y0, y1, x0, x1;
-                py_slice(iv, spread, side, y0, y1);
-                y0 = max(y0, row0);
-                y1 = min(y1, row1);
-                if (y0 >= y1) continue;
-                py_slice(iu, spread, side, x0, x1);
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
+        for (int h = 0; h < 2; ++h) {
+            int2 cur[kBatch];
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e) cur[e] = ent[h][e];
+            // the same half of the next round leaves now
+            const int next = base + (2 + h) * kBatch * kBandThreads;
+            if (next < total) {
+#pragma unroll
+                for (int e = 0; e < kBatch; ++e) {
+                    const int f = next + e * kBandThreads + threadIdx.x;
+                    ent[h][e] = lst[f < total ? f : 0];
+                }
             }
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e) splat(cur[e], base + (h * kBatch + e) * kBandThreads + threadIdx.x);
         }
     }
     __syncthreads();
+    STAMP(1);
     const double *P1 = cams1 + 12 * (int64_t)m;
     const double *P2 = cams2 + 12 * (int64_t)m;
     const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
     const CropXform cx = make_crop(c);
     const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
-    for (int p = threadIdx.x; p < npix; p += kBandThreads) {
-        const int o = DILATE ? (w == 4 ? window_owner4(owner, pw, p / side, p % side) : window_owner(owner, pw, p / side, p % side, w))
-                             : owner[p];
-        double2 val = make_double2(0.0, 0.0);
-        int64_t i = o - 1;
-        if (ORDERED && o > 0) {
-            i = inverse[o - 1];
-            if (i < 0 || i >= n) i = -1;
+    // Less than half of a map's pixels have an owner, and the float64 projection is what the resolve costs: each
+    // wave first finds the owners of kResolveChunk x 64 pixels (empty pixels get their zeros at once), queues the
+    // owned ones in its own stretch of LDS, and then projects with all lanes busy.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int2 *queue = reinterpret_cast<int2 *>(owner + ((nimg + 1) & ~1)) + wave * (64 * kResolveChunk);
+    for (int p0 = 0; p0 < npix; p0 += kBandThreads * kResolveChunk) {
+        int queued = 0;
+#pragma unroll
+        for (int c = 0; c < kResolveChunk; ++c) {
+            const int p = p0 + c * kBandThreads + (int)threadIdx.x;
+            int o = 0;
+            if (p < npix) {
+                const int ly = p / side, x = p % side;
+                o = DILATE ? (w == 4 ? window_owner4(owner, pw, ly, x) : window_owner(owner, pw, ly, x, w)) : owner[p];
+                if (o <= 0) out[p] = make_double2(0.0, 0.0);
+            }
+            const unsigned long long owned = __builtin_amdgcn_ballot_w64(o > 0);
+            if (o > 0) queue[queued + __popcll(owned & below)] = make_int2(p, o);
+            queued += __popcll(owned);
         }
-        if (i >= 0) {
-            const double x = pts[3 * i], y = pts[3 * i + 1], zz = pts[3 * i + 2];
-            double u1, v1, u2, v2, z;
-            project_point(P1, x, y, zz, u1, v1, z);
-            crop_apply(cx, tall, 1, u1, v1);
-            project_point(P2, x, y, zz, u2, v2, z);
-            crop_apply(cx, tall, 1, u2, v2);
-            val.x = u2 - u1;
-            val.y = v2 - v1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < queued; k += 64) {
+            const int2 item = queue[k];
+            const int p = item.x, o = item.y;
+            const int ly = p / side, x = p % side;
+            double2 val = make_double2(0.0, 0.0);
+            int64_t i = (DILATE ? (o >> 6) : o) - 1;
+            if (ORDERED) {
+                i = inverse[i];
+                if (i >= n) i = -1;
+            }
+            if (i >= 0) {
+                const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+                double u1, v1, u2, v2, z;
+                if (DILATE) {
+                    // the winning anchor sits dr rows and dc columns up-left of this pixel's last anchor, and an
+                    // anchor is its point's remapped pose-1 pixel less the spread: no second projection
+                    const int dr = (ly + w - 1 - (o >> 3)) & 7, dc = (x + w - 1 - o) & 7;
+                    u1 = (double)(x - dc + spread);
+                    v1 = (double)(row0 + ly - dr + spread);
+                } else {
+                    project_point(P1, px, py, pz, u1, v1, z);
+                    crop_apply(cx, tall, 1, u1, v1);
+                }
+                project_point(P2, px, py, pz, u2, v2, z);
+                crop_apply(cx, tall, 1, u2, v2);
+                val.x = u2 - u1;
+                val.y = v2 - v1;
+            }
+            out[p] = val;
         }
-        out[p] = val;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    STAMP(2);
 }
 
 __global__ __launch_bounds__(kThreads) void depth_owner_kernel(const double *__restrict__ pt_render,
@@ -700,13 +824,26 @@ extern "C" int ispa_zbuffer_visibility_packed(const double *pt_render, int64_t n
 namespace {
 int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
                         const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
-                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream,
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, void *workspace, void *stream,
                         const int32_t *rank = nullptr, const int32_t *inverse = nullptr);
 }
 
+// workspace of the two-launch path: the lengths of the per-(map, band) lists, then the lists themselves at their
+// worst-case size (every point of a map in one band)
+struct DisparityPlan {
+    size_t off_lists, total;
+};
+static DisparityPlan disparity_plan(int64_t n, int n_map) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    DisparityPlan p;
+    p.off_lists = up((size_t)n_map * kDispBands * sizeof(int32_t));
+    p.total = p.off_lists + (size_t)n_map * kDispBands * (size_t)n * sizeof(int2);
+    return p;
+}
+
 extern "C" size_t ispa_make_disparity_workspace_bytes(int64_t n, int n_map) {
-    if (n < 0 || n_map < 0) return 0;
-    return (size_t)n * (size_t)n_map * sizeof(int32_t);
+    if (n <= 0 || n_map <= 0) return 0;
+    return disparity_plan(n, n_map).total;
 }
 
 extern "C" int ispa_make_disparity_ws(const double *pts, int64_t n, const double *cams1, const double *cams2,
@@ -719,7 +856,7 @@ extern "C" int ispa_make_disparity_ws(const double *pts, int64_t n, const double
                           ispa_make_disparity_workspace_bytes(n, n_map));
     ISPA_REQUIRE(workspace != nullptr || n == 0 || n_map == 0, "null workspace");
     return make_disparity_impl(pts, n, cams1, cams2, n_map, depth, depth_per_map, H, W, ylim, xlim, relax, crop,
-                               crop_per_map, spread, flow, (int32_t *)workspace, stream);
+                               crop_per_map, spread, flow, workspace, stream);
 }
 
 extern "C" int ispa_make_disparity_ordered(const double *pts, const int32_t *rank, const int32_t *inverse, int64_t n,
@@ -734,7 +871,7 @@ extern "C" int ispa_make_disparity_ordered(const double *pts, const int32_t *ran
                           ispa_make_disparity_workspace_bytes(n, n_map));
     ISPA_REQUIRE(workspace != nullptr || n == 0 || n_map == 0, "null workspace");
     return make_disparity_impl(pts, n, cams1, cams2, n_map, depth, depth_per_map, H, W, ylim, xlim, relax, crop,
-                               crop_per_map, spread, flow, (int32_t *)workspace, stream, rank, inverse);
+                               crop_per_map, spread, flow, workspace, stream, rank, inverse);
 }
 
 extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const double *cams2,
@@ -748,7 +885,7 @@ extern "C" int ispa_make_disparity(const double *pts, int64_t n, const double *c
 namespace {
 int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const double *cams2, int n_map,
                         const float *depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
-                        const int32_t *crop, int crop_per_map, int spread, double *flow, int32_t *rec, void *stream,
+                        const int32_t *crop, int crop_per_map, int spread, double *flow, void *workspace, void *stream,
                         const int32_t *rank, const int32_t *inverse) {
     ISPA_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && n_map >= 0, "bad point count");
     ISPA_REQUIRE(spread >= 0 && spread <= 64, "bad spread");
@@ -769,25 +906,34 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
                                                 : reinterpret_cast<const void *>(&make_disparity_kernel<false>),
                                          kMaxBandLds, &configured[dilate]))
         return rc;
-    if (rec && n > 0) {
-        // with a workspace: the per-point part once per (map, point), then the band blocks on its records
+    if (workspace && n > 0) {
+        // with a workspace: the per-point part once per (map, point), then the band blocks on its lists
+        ISPA_REQUIRE(((uintptr_t)workspace & 7) == 0, "the workspace must be 8-byte aligned");
+        // the anchor values carry 6 position bits beside the point's rank
+        const bool dilate_ws = dilate && n < (1 << 25) - 1;
+        const size_t lds_ws = (dilate_ws ? dilate_bytes : (size_t)band_rows * side * sizeof(int)) + kResolveQueueBytes;
         static unsigned long long configured_b[4] = {0, 0, 0, 0};
         const bool ordered = rank != nullptr;
-        void (*bands)(const double *, int64_t, const double *, const double *, const int32_t *, const int32_t *, int,
-                      int, int, double *, const int32_t *, const int32_t *) =
-            ordered ? (dilate ? disparity_bands_kernel<true, true> : disparity_bands_kernel<false, true>)
-                    : (dilate ? disparity_bands_kernel<true, false> : disparity_bands_kernel<false, false>);
+        void (*bands)(const double *, int64_t, const double *, const double *, const int32_t *, int, int, double *,
+                      const int2 *, const int32_t *, const int32_t *) =
+            ordered ? (dilate_ws ? disparity_bands_kernel<true, true> : disparity_bands_kernel<false, true>)
+                    : (dilate_ws ? disparity_bands_kernel<true, false> : disparity_bands_kernel<false, false>);
         if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(bands), kMaxBandLds,
-                                             &configured_b[2 * ordered + dilate]))
+                                             &configured_b[2 * ordered + dilate_ws]))
             return rc;
+        const DisparityPlan plan = disparity_plan(n, n_map);
+        int32_t *counts = reinterpret_cast<int32_t *>(workspace);
+        int2 *lists = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace) + plan.off_lists);
         const ispa::TimingSlot timed = ispa::timing_begin(s);
+        ISPA_HIP(hipMemsetAsync(counts, 0, (size_t)n_map * kDispBands * sizeof(int32_t), s));
         const int nbx = (int)ispa::blocks_for(n, 256 * kPointsPerThread);
         const int64_t nblocks = (int64_t)((n_map + 7) / 8) * 8 * nbx;
         ISPA_REQUIRE(nblocks < (1ll << 31), "too many points x maps for one launch");
         hipLaunchKernelGGL(disparity_points_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, pts, n, cams1, depth,
-                           depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, n_map, nbx, rec);
-        hipLaunchKernelGGL(bands, dim3(nbands, n_map), dim3(kBandThreads), lds_bytes, s, pts, n, cams1, cams2, rec, crop,
-                           crop_per_map, spread, band_rows, flow, rank, inverse);
+                           depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, n_map, nbx, rank, spread, lists,
+                           counts);
+        hipLaunchKernelGGL(bands, dim3(kDispBands, n_map), dim3(kBandThreads), lds_ws, s, pts, n, cams1, cams2, crop,
+                           crop_per_map, spread, flow, lists, counts, inverse);
         ispa::timing_end(timed, s);
         return ispa::check_launch("disparity_bands_kernel");
     }
@@ -799,3 +945,14 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
     return ispa::check_launch("make_disparity_kernel");
 }
 }  // namespace
+
+#ifdef DISP_STAMP
+extern "C" int ispa_debug_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -106,7 +106,7 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
         c2 = dv.to_dev(cams2, torch.float64)
         crop_t = crops
         flow = dv.empty((n_map, FLOW_SIDE, FLOW_SIDE, 2), torch.float64)
-        # one word of workspace per (render, point): the per-point work then runs once, not once per band
+        # with a workspace the per-point work runs once per (render, point), not once per band
         need = _abi.lib.ispa_make_disparity_workspace_bytes(pts.shape[0], n_map)
         ws = dv.empty((max(need, 4),), torch.uint8)
         po = point_order
