@@ -339,10 +339,35 @@ constexpr int kDispBandRows = kBandPixels / (int)ispa_geom::kCropSide;
 constexpr int kDispBands = ((int)ispa_geom::kCropSide + kDispBandRows - 1) / kDispBandRows;
 constexpr int kResolveChunk = 4;             // x 64 pixels per wave between two queue drains
 constexpr size_t kResolveQueueBytes = (size_t)kBandThreads * kResolveChunk * sizeof(int2) + 8;
+// base + the number of lanes below this one whose bit is set in `mask`
+__device__ __forceinline__ int lanes_below(unsigned long long mask, int base) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, base));
+}
+
+// Per map, once: the crop transform (a float64 division that every thread of the two kernels below would
+// otherwise repeat) and the empty lists.
+struct DisparityMapSetup {
+    ispa_geom::CropXform cx;
+    int tall, unused;
+};
+__global__ __launch_bounds__(256) void disparity_setup_kernel(const int32_t *__restrict__ crop, int crop_per_map,
+                                                              int n_map, DisparityMapSetup *__restrict__ setup,
+                                                              int32_t *__restrict__ counts) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_map) return;
+    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
+    DisparityMapSetup su;
+    su.cx = ispa_geom::make_crop(c);
+    su.tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    su.unused = 0;
+    setup[m] = su;
+    for (int b = 0; b < kDispBands; ++b) counts[m * kDispBands + b] = 0;
+}
+
 __global__ __launch_bounds__(256) void disparity_points_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const float *__restrict__ depth,
-    int depth_per_map, int H, int W, int ylim, int xlim, double relax, const int32_t *__restrict__ crop,
-    int crop_per_map, int n_map, int nbx, const int32_t *__restrict__ rank, int spread, int2 *__restrict__ lists,
+    int depth_per_map, int H, int W, int ylim, int xlim, double relax, const DisparityMapSetup *__restrict__ setup,
+    int n_map, int nbx, const int32_t *__restrict__ rank, int spread, int2 *__restrict__ lists,
     int32_t *__restrict__ counts) {
     using namespace ispa_geom;
     // 1-D grid; workgroups b and b + 8 run on the same XCD.  All point blocks of a map go to one XCD and follow
@@ -354,11 +379,14 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
     __shared__ int s_cnt[kDispBands][4], s_base[kDispBands];
     const double *P1 = cams1 + 12 * (int64_t)m;
     const float *d = depth + (depth_per_map ? (int64_t)m * H * W : 0);
-    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
-    const CropXform cx = make_crop(c);
-    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    const CropXform cx = setup[m].cx;
+    const int tall = setup[m].tall;
     const int blk = wq % nbx;
-    const int64_t base = (int64_t)blk * (256 * kPointsPerThread) + threadIdx.x;
+    // this workgroup's points: 32-bit offsets from a uniform base
+    const int64_t first = (int64_t)blk * (256 * kPointsPerThread);
+    const int here = (int)min((int64_t)(256 * kPointsPerThread), n - first);
+    const double *pb = pts + 3 * first;
+    const int32_t *rb = rank ? rank + first : nullptr;
     constexpr int kBatch = 4;                     // loads, then gathers, of four points in flight together
     static_assert(kPointsPerThread == kBatch, "one batch per thread: the compaction below indexes it by e");
     int word[kBatch], tag[kBatch];
@@ -367,15 +395,15 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
         int rk[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)e * 256;
-            const int64_t j = i < n ? i : 0;
-            px[e] = pts[3 * j];
-            py[e] = pts[3 * j + 1];
-            pz[e] = pts[3 * j + 2];
-            rk[e] = rank ? rank[j] : (int)j;
+            const int l = (int)threadIdx.x + e * 256;
+            const int j = l < here ? l : 0;
+            px[e] = pb[3 * j];
+            py[e] = pb[3 * j + 1];
+            pz[e] = pb[3 * j + 2];
+            rk[e] = rb ? rb[j] : (int)first + j;
         }
         bool ok[kBatch], gate[kBatch];
-        int64_t at[kBatch];
+        int at[kBatch];                               // H * W fits 31 bits (checked by the caller)
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             double u, v, z;
@@ -387,24 +415,22 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
             word[e] = (cvt_i32_sat(vc) << 16) | (cvt_i32_sat(uc) & 0xffff);
             const int gx = cvt_i32_sat(u), gy = cvt_i32_sat(v);   // depth gate on the integer-valued pixel (pt2render.py:47-49)
             gate[e] = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
-            at[e] = gate[e] ? (int64_t)gy * W + gx : 0;
+            at[e] = gate[e] ? gy * W + gx : 0;
         }
         float texel[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) texel[e] = d[at[e]];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            const int64_t i = base + (int64_t)e * 256;
             const bool keep = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax);
             // a rank outside [0, n) drops its point (it can never own a pixel)
-            const bool listed = keep && i < n && (unsigned)rk[e] < (unsigned)n;
+            const bool listed = keep && (int)threadIdx.x + e * 256 < here && (unsigned)rk[e] < (unsigned)n;
             tag[e] = rk[e] + 1;
             word[e] = listed ? word[e] : -1;
         }
     }
     // ---- compaction: per band, this workgroup's kept points that can reach the band's rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
     unsigned long long mask[kDispBands][kBatch];
 #pragma unroll
     for (int bnd = 0; bnd < kDispBands; ++bnd) {
@@ -435,7 +461,7 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
         int2 *dst = lists + ((int64_t)m * kDispBands + bnd) * n;
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            if ((mask[bnd][e] >> lane) & 1ull) dst[at + __popcll(mask[bnd][e] & below)] = make_int2(word[e], tag[e]);
+            if ((mask[bnd][e] >> lane) & 1ull) dst[lanes_below(mask[bnd][e], at)] = make_int2(word[e], tag[e]);
             at += __popcll(mask[bnd][e]);
         }
     }
@@ -454,7 +480,7 @@ __device__ unsigned long long g_stamp[8];
 template <bool DILATE, bool ORDERED>
 __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
-    const int32_t *__restrict__ crop, int crop_per_map, int spread, double *__restrict__ flow,
+    const DisparityMapSetup *__restrict__ setup, int spread, double *__restrict__ flow,
     const int2 *__restrict__ lists, const int32_t *__restrict__ counts, const int32_t *__restrict__ inverse) {
     using namespace ispa_geom;
     extern __shared__ int owner[];
@@ -463,7 +489,8 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     const int row0 = blockIdx.x * kDispBandRows;
     const int row1 = min(row0 + kDispBandRows, side);
     const int npix = (row1 - row0) * side;
-    const int w = 2 * spread, pw = side + w - 1;         // DILATE: anchor image (band rows + w - 1) x pw
+    // DILATE: anchor image of (band rows + w - 1) rows of side + w - 1 anchors, at a pitch of whole 16-byte groups
+    const int w = 2 * spread, pw = (side + w - 1 + 3) & ~3;
     const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
     const int2 *lst = lists + ((int64_t)m * kDispBands + blockIdx.x) * n;
     // Two batches of entries per thread travel while the image is cleared, and they are asked for before the
@@ -530,17 +557,42 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
     }
     __syncthreads();
     STAMP(1);
+    if (DILATE && w == 4) {
+        // The window maximum is separable.  In place: every anchor becomes the maximum of itself and its three
+        // right-hand neighbours (16-byte reads and writes, four anchors per thread and round; all rounds are read
+        // before the first is written), and a pixel then takes the maximum of four values of its column.
+        constexpr int kGroups = side / 4;                          // per row; the anchors right of them are only read
+        constexpr int kRounds = ((kDispBandRows + 3) * kGroups + kBandThreads - 1) / kBandThreads;
+        const int ngroups = (row1 - row0 + 3) * kGroups;
+        int4 h[kRounds];
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int g = k * kBandThreads + (int)threadIdx.x;
+            if (g < ngroups) {
+                const int *src = owner + (g / kGroups) * pw + (g % kGroups) * 4;
+                const int4 a = *reinterpret_cast<const int4 *>(src), b = *reinterpret_cast<const int4 *>(src + 4);
+                const int zw = max(a.z, a.w), xy = max(b.x, b.y);
+                h[k] = make_int4(max(max(a.x, a.y), zw), max(max(a.y, b.x), zw), max(zw, xy), max(max(a.w, b.z), xy));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int g = k * kBandThreads + (int)threadIdx.x;
+            if (g < ngroups) *reinterpret_cast<int4 *>(owner + (g / kGroups) * pw + (g % kGroups) * 4) = h[k];
+        }
+        __syncthreads();
+    }
+    STAMP(3);
     const double *P1 = cams1 + 12 * (int64_t)m;
     const double *P2 = cams2 + 12 * (int64_t)m;
-    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
-    const CropXform cx = make_crop(c);
-    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    const CropXform cx = setup[m].cx;
+    const int tall = setup[m].tall;
     double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     // Less than half of a map's pixels have an owner, and the float64 projection is what the resolve costs: each
     // wave first finds the owners of kResolveChunk x 64 pixels (empty pixels get their zeros at once), queues the
     // owned ones in its own stretch of LDS, and then projects with all lanes busy.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
     int2 *queue = reinterpret_cast<int2 *>(owner + ((nimg + 1) & ~1)) + wave * (64 * kResolveChunk);
     for (int p0 = 0; p0 < npix; p0 += kBandThreads * kResolveChunk) {
         int queued = 0;
@@ -550,11 +602,16 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
             int o = 0;
             if (p < npix) {
                 const int ly = p / side, x = p % side;
-                o = DILATE ? (w == 4 ? window_owner4(owner, pw, ly, x) : window_owner(owner, pw, ly, x, w)) : owner[p];
+                if (DILATE && w == 4) {
+                    const int *col = owner + ly * pw + x;
+                    o = max(max(col[0], col[pw]), max(col[2 * pw], col[3 * pw]));
+                } else {
+                    o = DILATE ? window_owner(owner, pw, ly, x, w) : owner[p];
+                }
                 if (o <= 0) out[p] = make_double2(0.0, 0.0);
             }
             const unsigned long long owned = __builtin_amdgcn_ballot_w64(o > 0);
-            if (o > 0) queue[queued + __popcll(owned & below)] = make_int2(p, o);
+            if (o > 0) queue[lanes_below(owned, queued)] = make_int2(p, o);
             queued += __popcll(owned);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -828,15 +885,16 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
                         const int32_t *rank = nullptr, const int32_t *inverse = nullptr);
 }
 
-// workspace of the two-launch path: the lengths of the per-(map, band) lists, then the lists themselves at their
-// worst-case size (every point of a map in one band)
+// workspace of the path with lists: their lengths per (map, band), the per-map set-up, then the lists themselves
+// at their worst-case size (every point of a map in one band)
 struct DisparityPlan {
-    size_t off_lists, total;
+    size_t off_setup, off_lists, total;
 };
 static DisparityPlan disparity_plan(int64_t n, int n_map) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     DisparityPlan p;
-    p.off_lists = up((size_t)n_map * kDispBands * sizeof(int32_t));
+    p.off_setup = up((size_t)n_map * kDispBands * sizeof(int32_t));
+    p.off_lists = p.off_setup + up((size_t)n_map * sizeof(DisparityMapSetup));
     p.total = p.off_lists + (size_t)n_map * kDispBands * (size_t)n * sizeof(int2);
     return p;
 }
@@ -891,6 +949,7 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
     ISPA_REQUIRE(spread >= 0 && spread <= 64, "bad spread");
     if (n_map == 0) return ISPA_OK;
     ISPA_REQUIRE(cams1 && cams2 && depth && crop && flow && (n == 0 || pts), "null pointer");
+    ISPA_REQUIRE((int64_t)H * W < (1ll << 31), "depth map of %d x %d texels is too large", H, W);
     ISPA_REQUIRE(H > 0 && W > 0 && ylim >= 1 && ylim <= H && xlim >= 1 && xlim <= W,
                  "visibility gate (%d,%d) exceeds the depth map (%d,%d)", ylim, xlim, H, W);
     ISPA_REQUIRE(n_map <= 65535, "too many maps per call (%d)", n_map);
@@ -911,10 +970,12 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
         ISPA_REQUIRE(((uintptr_t)workspace & 7) == 0, "the workspace must be 8-byte aligned");
         // the anchor values carry 6 position bits beside the point's rank
         const bool dilate_ws = dilate && n < (1 << 25) - 1;
-        const size_t lds_ws = (dilate_ws ? dilate_bytes : (size_t)band_rows * side * sizeof(int)) + kResolveQueueBytes;
+        const size_t pitch = (size_t)((side + 2 * spread - 1 + 3) & ~3);
+        const size_t lds_ws = (dilate_ws ? (size_t)(band_rows + 2 * spread - 1) * pitch * sizeof(int)
+                                         : (size_t)band_rows * side * sizeof(int)) + kResolveQueueBytes;
         static unsigned long long configured_b[4] = {0, 0, 0, 0};
         const bool ordered = rank != nullptr;
-        void (*bands)(const double *, int64_t, const double *, const double *, const int32_t *, int, int, double *,
+        void (*bands)(const double *, int64_t, const double *, const double *, const DisparityMapSetup *, int, double *,
                       const int2 *, const int32_t *, const int32_t *) =
             ordered ? (dilate_ws ? disparity_bands_kernel<true, true> : disparity_bands_kernel<false, true>)
                     : (dilate_ws ? disparity_bands_kernel<true, false> : disparity_bands_kernel<false, false>);
@@ -923,17 +984,18 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
             return rc;
         const DisparityPlan plan = disparity_plan(n, n_map);
         int32_t *counts = reinterpret_cast<int32_t *>(workspace);
+        DisparityMapSetup *setup = reinterpret_cast<DisparityMapSetup *>(reinterpret_cast<char *>(workspace) + plan.off_setup);
         int2 *lists = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace) + plan.off_lists);
         const ispa::TimingSlot timed = ispa::timing_begin(s);
-        ISPA_HIP(hipMemsetAsync(counts, 0, (size_t)n_map * kDispBands * sizeof(int32_t), s));
+        hipLaunchKernelGGL(disparity_setup_kernel, dim3((unsigned)ispa::blocks_for(n_map, 256)), dim3(256), 0, s, crop,
+                           crop_per_map, n_map, setup, counts);
         const int nbx = (int)ispa::blocks_for(n, 256 * kPointsPerThread);
         const int64_t nblocks = (int64_t)((n_map + 7) / 8) * 8 * nbx;
         ISPA_REQUIRE(nblocks < (1ll << 31), "too many points x maps for one launch");
         hipLaunchKernelGGL(disparity_points_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, pts, n, cams1, depth,
-                           depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, n_map, nbx, rank, spread, lists,
-                           counts);
-        hipLaunchKernelGGL(bands, dim3(kDispBands, n_map), dim3(kBandThreads), lds_ws, s, pts, n, cams1, cams2, crop,
-                           crop_per_map, spread, flow, lists, counts, inverse);
+                           depth_per_map, H, W, ylim, xlim, relax, setup, n_map, nbx, rank, spread, lists, counts);
+        hipLaunchKernelGGL(bands, dim3(kDispBands, n_map), dim3(kBandThreads), lds_ws, s, pts, n, cams1, cams2, setup,
+                           spread, flow, lists, counts, inverse);
         ispa::timing_end(timed, s);
         return ispa::check_launch("disparity_bands_kernel");
     }
