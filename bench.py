@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--one-launch", action="store_true",
                     help="disparity: the one-launch kernel without a workspace (ispa_make_disparity) instead of the "
-                         "two-launch form (ispa_make_disparity_ws)")
+                         "form with a workspace (ispa_make_disparity_ws)")
     ap.add_argument("--model", choices=["chair", "cube"], default="chair",
                     help="geometry workloads: the synthetic model the points come from. chair: area-weighted surface "
                          "samples of a box-built chair mesh (the reference samples CAD mesh surfaces, "
@@ -385,7 +385,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
             # fused: points read once per map, one depth gather per point, the flow map written
             alg_bytes = [(24.0 * n + 4.0 * n + 802816.0) * M]
             names = ["make_disparity" if args.one_launch else "make_disparity_ws"]
-            workload = (f"make_disparity flow maps, fused ({'one launch' if args.one_launch else 'two launches, 16 B of workspace per point and map'}): "
+            workload = (f"make_disparity flow maps, fused ({'one launch, no workspace' if args.one_launch else 'with 16 B of workspace per point and map: one workgroup per map when the maps fill the chip, else per-band lists in three launches'}): "
                         f"{M} renders per GPU per step of a {n}-point "
                         f"model (projection at 2 poses, depth visibility, crop, 224x224x2 float64 flow splat)")
     for _ in range(args.warmup):

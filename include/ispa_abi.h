@@ -143,11 +143,12 @@ int ispa_make_disparity(const double *pts, int64_t n, const double *cams1, const
                         double *flow, void *stream);
 
 /* The same body with a workspace of ispa_make_disparity_workspace_bytes(n, n_map), about 16 bytes per
- * (map, point) and 8-byte aligned: projection, crop and visibility run once per (map, point) in a launch of
- * their own, which leaves per half-map band a list of the points that can write into it (room for the worst
- * case; a map's visible points are what is written and read back); the per-map splat then reads its lists
- * instead of projecting every point once per band.  Same flow maps, bit for bit; about a third faster at
- * 100 000 points.  The workspace needs no initialisation and holds nothing between calls. */
+ * (map, point) and 8-byte aligned: projection, crop and visibility run once per (map, point) instead of once
+ * per half-map band, and leave lists of the visible points for the bands to read (room for the worst case; a
+ * map's visible points are what is written and read back).  A call whose maps fill the chip (at least 85 % of
+ * the compute units in every round of n_map / compute units) runs as one launch with a workgroup per map;
+ * other calls run a launch over (map, point) and a launch over (map, band).  Same flow maps, bit for bit; about
+ * a third faster at 100 000 points.  The workspace needs no initialisation and holds nothing between calls. */
 size_t ispa_make_disparity_workspace_bytes(int64_t n, int n_map);
 int ispa_make_disparity_ws(const double *pts, int64_t n, const double *cams1, const double *cams2,
                            int n_map, const float *depth, int depth_per_map, int H, int W, int ylim,

@@ -467,109 +467,75 @@ __global__ __launch_bounds__(256) void disparity_points_kernel(
     }
 }
 
-#ifdef DISP_STAMP
-__device__ unsigned long long g_stamp[8];
-#define STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_stamp[k], t_ - t0_); t0_ = t_; } } while (0)
-#else
-#define STAMP(k)
-#endif
-// ORDERED: the points arrive in a processing order of the caller's choice (e.g. along a space-filling curve, so
-// that the points kernel's depth gathers coalesce) and rank[i] is point i's index in the reference's order: the
-// kept point with the highest RANK wins a pixel, and inverse[rank] finds it again for the flow value.  Ranks
-// outside [0, n) drop their point and a bad inverse entry leaves the pixel empty: no read outside the arrays.
-template <bool DILATE, bool ORDERED>
-__global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
-    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
-    const DisparityMapSetup *__restrict__ setup, int spread, double *__restrict__ flow,
-    const int2 *__restrict__ lists, const int32_t *__restrict__ counts, const int32_t *__restrict__ inverse) {
-    using namespace ispa_geom;
-    extern __shared__ int owner[];
-    constexpr int side = (int)kCropSide;
-    const int m = blockIdx.y;
-    const int row0 = blockIdx.x * kDispBandRows;
-    const int row1 = min(row0 + kDispBandRows, side);
-    const int npix = (row1 - row0) * side;
+// ---- one band of one map in LDS: shared by the kernel that reads lists and the kernel that owns a whole map
+struct BandGeom {
+    int row0, row1, npix;     // map rows [row0, row1) and their pixel count
+    int w, pw, nimg;          // DILATE: window side, pitch and size of the anchor image
+};
+template <bool DILATE>
+__device__ __forceinline__ BandGeom band_geom(int band, int spread) {
+    constexpr int side = (int)ispa_geom::kCropSide;
+    BandGeom g;
+    g.row0 = band * kDispBandRows;
+    g.row1 = min(g.row0 + kDispBandRows, side);
+    g.npix = (g.row1 - g.row0) * side;
     // DILATE: anchor image of (band rows + w - 1) rows of side + w - 1 anchors, at a pitch of whole 16-byte groups
-    const int w = 2 * spread, pw = (side + w - 1 + 3) & ~3;
-    const int nimg = DILATE ? (row1 - row0 + w - 1) * pw : npix;
-    const int2 *lst = lists + ((int64_t)m * kDispBands + blockIdx.x) * n;
-    // Two batches of entries per thread travel while the image is cleared, and they are asked for before the
-    // list's length is known (a list has room for n entries, so the read is in bounds; what lies beyond the
-    // length is dropped below): the length and the entries arrive together instead of one after the other.
-    constexpr int kBatch = 8;
-    int2 ent[2][kBatch];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const int f = (h * kBatch + e) * kBandThreads + threadIdx.x;
-            ent[h][e] = lst[f < n ? f : 0];
-        }
-    const int total = min(counts[m * kDispBands + blockIdx.x], (int)n);
-#ifdef DISP_STAMP
-    unsigned long long t0_ = __builtin_readcyclecounter();
-#endif
-    for (int p = threadIdx.x; p < nimg; p += kBandThreads) owner[p] = 0;
-    __syncthreads();
-    STAMP(0);
-    auto splat = [&](const int2 en, int f) {
-        if (f >= total || en.x < 0) return;
-        const int iu = en.x & 0xffff, iv = en.x >> 16;
-        const int tag = en.y;
-        if (DILATE) {
-            // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
-            // below the spread and anchored at c - spread otherwise
-            if (iu < spread || iv < spread || iu >= side + spread || iv >= side + spread) return;
-            const int lr = iv - spread - (row0 - (w - 1)), lc = iu - spread + w - 1;
-            if (lr < 0 || iv - spread >= row1) return;
-            // the anchor's own position (mod 8) rides in the low bits: the pixel that finds this value as
-            // its window maximum knows which of its w x w anchors it came from, i.e. the owner's pixel
-            atomicMax(&owner[lr * pw + lc], (tag << 6) | ((lr & 7) << 3) | (lc & 7));
-        } else {
-            int y0, y1, x0, x1;
-            py_slice(iv, spread, side, y0, y1);
-            y0 = max(y0, row0);
-            y1 = min(y1, row1);
-            if (y0 >= y1) return;
-            py_slice(iu, spread, side, x0, x1);
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - row0) * side + x], tag);
-        }
-    };
-    for (int base = 0; base < total; base += 2 * kBandThreads * kBatch) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int2 cur[kBatch];
-#pragma unroll
-            for (int e = 0; e < kBatch; ++e) cur[e] = ent[h][e];
-            // the same half of the next round leaves now
-            const int next = base + (2 + h) * kBatch * kBandThreads;
-            if (next < total) {
-#pragma unroll
-                for (int e = 0; e < kBatch; ++e) {
-                    const int f = next + e * kBandThreads + threadIdx.x;
-                    ent[h][e] = lst[f < total ? f : 0];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < kBatch; ++e) splat(cur[e], base + (h * kBatch + e) * kBandThreads + threadIdx.x);
-        }
+    g.w = 2 * spread;
+    g.pw = (side + g.w - 1 + 3) & ~3;
+    g.nimg = DILATE ? (g.row1 - g.row0 + g.w - 1) * g.pw : g.npix;
+    return g;
+}
+
+// a kept point (its record and tag) writes what it owns of the band
+template <bool DILATE>
+__device__ __forceinline__ void band_splat(int *owner, const BandGeom &g, int spread, int word, int tag) {
+    constexpr int side = (int)ispa_geom::kCropSide;
+    if (word < 0) return;
+    const int iu = word & 0xffff, iv = word >> 16;
+    if (DILATE) {
+        // as in make_disparity_kernel: for remapped coordinates in [0, side] the Python slice is empty
+        // below the spread and anchored at c - spread otherwise
+        if (iu < spread || iv < spread || iu >= side + spread || iv >= side + spread) return;
+        const int lr = iv - spread - (g.row0 - (g.w - 1)), lc = iu - spread + g.w - 1;
+        if (lr < 0 || iv - spread >= g.row1) return;
+        // the anchor's own position (mod 8) rides in the low bits: the pixel that finds this value as
+        // its window maximum knows which of its w x w anchors it came from, i.e. the owner's pixel
+        atomicMax(&owner[lr * g.pw + lc], (tag << 6) | ((lr & 7) << 3) | (lc & 7));
+    } else {
+        int y0, y1, x0, x1;
+        py_slice(iv, spread, side, y0, y1);
+        y0 = max(y0, g.row0);
+        y1 = min(y1, g.row1);
+        if (y0 >= y1) return;
+        py_slice(iu, spread, side, x0, x1);
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) atomicMax(&owner[(y - g.row0) * side + x], tag);
     }
-    __syncthreads();
-    STAMP(1);
+}
+
+// After the last band_splat (the caller has synchronised): owners of the band's pixels, flow values, stores.
+// Called by all threads of the workgroup; `owner` has room for the image and kResolveQueueBytes behind it.
+template <bool DILATE, bool ORDERED>
+__device__ __forceinline__ void band_resolve(int *owner, const BandGeom &g, int spread, const double *__restrict__ pts,
+                                             int64_t n, const double *__restrict__ P1, const double *__restrict__ P2,
+                                             const ispa_geom::CropXform &cx, int tall, double2 *__restrict__ out,
+                                             const int32_t *__restrict__ inverse) {
+    using namespace ispa_geom;
+    constexpr int side = (int)kCropSide;
+    const int w = g.w, pw = g.pw;
     if (DILATE && w == 4) {
         // The window maximum is separable.  In place: every anchor becomes the maximum of itself and its three
         // right-hand neighbours (16-byte reads and writes, four anchors per thread and round; all rounds are read
         // before the first is written), and a pixel then takes the maximum of four values of its column.
         constexpr int kGroups = side / 4;                          // per row; the anchors right of them are only read
         constexpr int kRounds = ((kDispBandRows + 3) * kGroups + kBandThreads - 1) / kBandThreads;
-        const int ngroups = (row1 - row0 + 3) * kGroups;
+        const int ngroups = (g.row1 - g.row0 + 3) * kGroups;
         int4 h[kRounds];
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int g = k * kBandThreads + (int)threadIdx.x;
-            if (g < ngroups) {
-                const int *src = owner + (g / kGroups) * pw + (g % kGroups) * 4;
+            const int q = k * kBandThreads + (int)threadIdx.x;
+            if (q < ngroups) {
+                const int *src = owner + (q / kGroups) * pw + (q % kGroups) * 4;
                 const int4 a = *reinterpret_cast<const int4 *>(src), b = *reinterpret_cast<const int4 *>(src + 4);
                 const int zw = max(a.z, a.w), xy = max(b.x, b.y);
                 h[k] = make_int4(max(max(a.x, a.y), zw), max(max(a.y, b.x), zw), max(zw, xy), max(max(a.w, b.z), xy));
@@ -578,29 +544,23 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int g = k * kBandThreads + (int)threadIdx.x;
-            if (g < ngroups) *reinterpret_cast<int4 *>(owner + (g / kGroups) * pw + (g % kGroups) * 4) = h[k];
+            const int q = k * kBandThreads + (int)threadIdx.x;
+            if (q < ngroups) *reinterpret_cast<int4 *>(owner + (q / kGroups) * pw + (q % kGroups) * 4) = h[k];
         }
         __syncthreads();
     }
-    STAMP(3);
-    const double *P1 = cams1 + 12 * (int64_t)m;
-    const double *P2 = cams2 + 12 * (int64_t)m;
-    const CropXform cx = setup[m].cx;
-    const int tall = setup[m].tall;
-    double2 *out = reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + row0) * side;
     // Less than half of a map's pixels have an owner, and the float64 projection is what the resolve costs: each
     // wave first finds the owners of kResolveChunk x 64 pixels (empty pixels get their zeros at once), queues the
     // owned ones in its own stretch of LDS, and then projects with all lanes busy.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int2 *queue = reinterpret_cast<int2 *>(owner + ((nimg + 1) & ~1)) + wave * (64 * kResolveChunk);
-    for (int p0 = 0; p0 < npix; p0 += kBandThreads * kResolveChunk) {
+    int2 *queue = reinterpret_cast<int2 *>(owner + ((g.nimg + 1) & ~1)) + wave * (64 * kResolveChunk);
+    for (int p0 = 0; p0 < g.npix; p0 += kBandThreads * kResolveChunk) {
         int queued = 0;
 #pragma unroll
         for (int c = 0; c < kResolveChunk; ++c) {
             const int p = p0 + c * kBandThreads + (int)threadIdx.x;
             int o = 0;
-            if (p < npix) {
+            if (p < g.npix) {
                 const int ly = p / side, x = p % side;
                 if (DILATE && w == 4) {
                     const int *col = owner + ly * pw + x;
@@ -634,7 +594,7 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
                     // anchor is its point's remapped pose-1 pixel less the spread: no second projection
                     const int dr = (ly + w - 1 - (o >> 3)) & 7, dc = (x + w - 1 - o) & 7;
                     u1 = (double)(x - dc + spread);
-                    v1 = (double)(row0 + ly - dr + spread);
+                    v1 = (double)(g.row0 + ly - dr + spread);
                 } else {
                     project_point(P1, px, py, pz, u1, v1, z);
                     crop_apply(cx, tall, 1, u1, v1);
@@ -649,7 +609,190 @@ __global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    STAMP(2);
+}
+
+// ORDERED: the points arrive in a processing order of the caller's choice (e.g. along a space-filling curve, so
+// that the points kernel's depth gathers coalesce) and rank[i] is point i's index in the reference's order: the
+// kept point with the highest RANK wins a pixel, and inverse[rank] finds it again for the flow value.  Ranks
+// outside [0, n) drop their point and a bad inverse entry leaves the pixel empty: no read outside the arrays.
+template <bool DILATE, bool ORDERED>
+__global__ __launch_bounds__(kBandThreads) void disparity_bands_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
+    const DisparityMapSetup *__restrict__ setup, int spread, double *__restrict__ flow,
+    const int2 *__restrict__ lists, const int32_t *__restrict__ counts, const int32_t *__restrict__ inverse) {
+    extern __shared__ int owner[];
+    constexpr int side = (int)ispa_geom::kCropSide;
+    const int m = blockIdx.y;
+    const BandGeom g = band_geom<DILATE>(blockIdx.x, spread);
+    const int2 *lst = lists + ((int64_t)m * kDispBands + blockIdx.x) * n;
+    // Two batches of entries per thread travel while the image is cleared, and they are asked for before the
+    // list's length is known (a list has room for n entries, so the read is in bounds; what lies beyond the
+    // length is dropped below): the length and the entries arrive together instead of one after the other.
+    constexpr int kBatch = 8;
+    int2 ent[2][kBatch];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int f = (h * kBatch + e) * kBandThreads + threadIdx.x;
+            ent[h][e] = lst[f < n ? f : 0];
+        }
+    const int total = min(counts[m * kDispBands + blockIdx.x], (int)n);
+    for (int p = threadIdx.x; p < g.nimg; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 2 * kBandThreads * kBatch) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int2 cur[kBatch];
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e) cur[e] = ent[h][e];
+            // the same half of the next round leaves now
+            const int next = base + (2 + h) * kBatch * kBandThreads;
+            if (next < total) {
+#pragma unroll
+                for (int e = 0; e < kBatch; ++e) {
+                    const int f = next + e * kBandThreads + threadIdx.x;
+                    ent[h][e] = lst[f < total ? f : 0];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < kBatch; ++e) {
+                const int f = base + (h * kBatch + e) * kBandThreads + threadIdx.x;
+                band_splat<DILATE>(owner, g, spread, f < total ? cur[e].x : -1, cur[e].y);
+            }
+        }
+    }
+    __syncthreads();
+    band_resolve<DILATE, ORDERED>(owner, g, spread, pts, n, cams1 + 12 * (int64_t)m, cams2 + 12 * (int64_t)m,
+                                  setup[m].cx, setup[m].tall,
+                                  reinterpret_cast<double2 *>(flow) + ((int64_t)m * side + g.row0) * side, inverse);
+}
+
+// One workgroup per MAP, for calls with about as many maps as the chip has compute units (or whole multiples):
+// the workgroup projects the map's points once, splats the first band's points straight into LDS while each wave
+// keeps the second band's in a list of its own (global memory that only this wave touches: no counters, no
+// atomics, read back from the L2 it was written to), resolves the first band, then splats and resolves the second.
+// One launch, and no list ever waits in HBM for another kernel.
+template <bool DILATE, bool ORDERED>
+__global__ __launch_bounds__(kBandThreads) void disparity_maps_kernel(
+    const double *__restrict__ pts, int64_t n, const double *__restrict__ cams1, const double *__restrict__ cams2,
+    const float *__restrict__ depth, int depth_per_map, int H, int W, int ylim, int xlim, double relax,
+    const int32_t *__restrict__ crop, int crop_per_map, int spread, double *__restrict__ flow,
+    int2 *__restrict__ lists, int64_t wave_pitch, const int32_t *__restrict__ rank, const int32_t *__restrict__ inverse) {
+    using namespace ispa_geom;
+    static_assert(kDispBands == 2, "the first band goes to LDS, the second to the lists");
+    extern __shared__ int owner[];
+    constexpr int side = (int)kCropSide;
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *P1 = cams1 + 12 * (int64_t)m;
+    const double *P2 = cams2 + 12 * (int64_t)m;
+    const float *d = depth + (depth_per_map ? (int64_t)m * H * W : 0);
+    const int32_t *c = crop + (crop_per_map ? 4 * (int64_t)m : 0);
+    const CropXform cx = make_crop(c);
+    const int tall = (c[1] - c[0]) >= (c[3] - c[2]);
+    double2 *out = reinterpret_cast<double2 *>(flow) + (int64_t)m * side * side;
+    BandGeom g = band_geom<DILATE>(0, spread);
+    for (int p = threadIdx.x; p < g.nimg; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    int2 *mine = lists + ((int64_t)m * (kBandThreads / 64) + wave) * wave_pitch;
+    int listed1 = 0;                                  // entries in this wave's list (uniform)
+    constexpr int kBatch = 4;                         // loads, then gathers, of four points in flight together
+    double nx[kBatch], ny[kBatch], nz[kBatch];        // the next round's points travel during this round's work
+    int nrk[kBatch];
+    auto fetch = [&](int64_t first) {
+        const int here = (int)min((int64_t)(kBandThreads * kBatch), n - first);
+        const double *pb = pts + 3 * first;
+        const int32_t *rb = rank ? rank + first : nullptr;
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int l = (int)threadIdx.x + e * kBandThreads;
+            const int j = l < here ? l : 0;
+            nx[e] = pb[3 * j];
+            ny[e] = pb[3 * j + 1];
+            nz[e] = pb[3 * j + 2];
+            nrk[e] = rb ? rb[j] : (int)first + j;
+        }
+    };
+    if (n > 0) fetch(0);
+    for (int64_t first = 0; first < n; first += kBandThreads * kBatch) {
+        const int here = (int)min((int64_t)(kBandThreads * kBatch), n - first);
+        double px[kBatch], py[kBatch], pz[kBatch];
+        int rk[kBatch], word[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            px[e] = nx[e];
+            py[e] = ny[e];
+            pz[e] = nz[e];
+            rk[e] = nrk[e];
+        }
+        if (first + kBandThreads * kBatch < n) fetch(first + kBandThreads * kBatch);
+        bool ok[kBatch], gate[kBatch];
+        int at[kBatch];                               // H * W fits 31 bits (checked by the caller)
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            double u, v, z;
+            project_point(P1, px[e], py[e], pz[e], u, v, z);
+            pz[e] = z;
+            double uc = u, vc = v;
+            ok[e] = crop_apply(cx, tall, 1, uc, vc);
+            word[e] = (cvt_i32_sat(vc) << 16) | (cvt_i32_sat(uc) & 0xffff);
+            const int gx = cvt_i32_sat(u), gy = cvt_i32_sat(v);   // pt2render.py:47-49
+            gate[e] = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
+            at[e] = gate[e] ? gy * W + gx : 0;
+        }
+        float texel[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) texel[e] = d[at[e]];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const bool keep = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax);
+            const bool listed = keep && (int)threadIdx.x + e * kBandThreads < here && (unsigned)rk[e] < (unsigned)n;
+            const int rec = listed ? word[e] : -1, tag = rk[e] + 1;
+            band_splat<DILATE>(owner, g, spread, rec, tag);
+            // the rows a point writes lie in [iv - spread, iv + spread)
+            const bool second = rec >= 0 && (rec >> 16) + spread >= kDispBandRows;
+            const unsigned long long take = __builtin_amdgcn_ballot_w64(second);
+            if (second) mine[lanes_below(take, listed1)] = make_int2(rec, tag);
+            listed1 += __popcll(take);
+        }
+    }
+    __syncthreads();
+    band_resolve<DILATE, ORDERED>(owner, g, spread, pts, n, P1, P2, cx, tall, out, inverse);
+    // this wave's list, written above, is read back by the same wave: no wider scope is needed (a fence at
+    // device scope would write back and invalidate the L2 that 31 other workgroups are working from)
+    __threadfence_block();
+    // sixteen entries per lane in flight, the first sixteen while the image is cleared, and the next sixteen leave
+    // before these are used
+    constexpr int kDepth = 16;
+    int2 en[kDepth];
+#pragma unroll
+    for (int e = 0; e < kDepth; ++e) {
+        const int k = e * 64 + lane;
+        en[e] = k < listed1 ? mine[k] : make_int2(-1, 0);
+    }
+    __syncthreads();
+    g = band_geom<DILATE>(1, spread);
+    for (int p = threadIdx.x; p < g.nimg; p += kBandThreads) owner[p] = 0;
+    __syncthreads();
+    {
+        for (int k0 = 0; k0 < listed1; k0 += 64 * kDepth) {
+            int2 cur[kDepth];
+#pragma unroll
+            for (int e = 0; e < kDepth; ++e) cur[e] = en[e];
+            if (k0 + 64 * kDepth < listed1) {
+#pragma unroll
+                for (int e = 0; e < kDepth; ++e) {
+                    const int k = k0 + (kDepth + e) * 64 + lane;
+                    en[e] = k < listed1 ? mine[k] : make_int2(-1, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < kDepth; ++e) band_splat<DILATE>(owner, g, spread, cur[e].x, cur[e].y);
+        }
+    }
+    __syncthreads();
+    band_resolve<DILATE, ORDERED>(owner, g, spread, pts, n, P1, P2, cx, tall, out + (int64_t)g.row0 * side, inverse);
 }
 
 __global__ __launch_bounds__(kThreads) void depth_owner_kernel(const double *__restrict__ pt_render,
@@ -885,8 +1028,12 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
                         const int32_t *rank = nullptr, const int32_t *inverse = nullptr);
 }
 
-// workspace of the path with lists: their lengths per (map, band), the per-map set-up, then the lists themselves
-// at their worst-case size (every point of a map in one band)
+// entries a wave of disparity_maps_kernel can list: 4 x 64 per round of 4 x 1024 points
+static size_t disparity_wave_pitch(int64_t n) {
+    return (size_t)((n + 4 * kBandThreads - 1) / (4 * kBandThreads)) * 256;
+}
+// workspace of the paths with lists: their lengths per (map, band), the per-map set-up, then the lists themselves
+// at their worst-case size
 struct DisparityPlan {
     size_t off_setup, off_lists, total;
 };
@@ -895,7 +1042,9 @@ static DisparityPlan disparity_plan(int64_t n, int n_map) {
     DisparityPlan p;
     p.off_setup = up((size_t)n_map * kDispBands * sizeof(int32_t));
     p.off_lists = p.off_setup + up((size_t)n_map * sizeof(DisparityMapSetup));
-    p.total = p.off_lists + (size_t)n_map * kDispBands * (size_t)n * sizeof(int2);
+    // a list per (map, band) with room for every point, or a list per (map, wave) of disparity_maps_kernel
+    const size_t per_map = std::max((size_t)kDispBands * (size_t)n, (size_t)(kBandThreads / 64) * disparity_wave_pitch(n));
+    p.total = p.off_lists + (size_t)n_map * per_map * sizeof(int2);
     return p;
 }
 
@@ -983,6 +1132,28 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
                                              &configured_b[2 * ordered + dilate_ws]))
             return rc;
         const DisparityPlan plan = disparity_plan(n, n_map);
+        // One workgroup per map when that keeps the chip busy: at least 85 % of the compute units in every round.
+        int dev = 0, cus = 0;
+        ISPA_HIP(hipGetDevice(&dev));
+        ISPA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int rounds = (n_map + cus - 1) / std::max(cus, 1);
+        if (cus > 0 && (int64_t)n_map * 100 >= (int64_t)rounds * cus * 85) {
+            static unsigned long long configured_m[4] = {0, 0, 0, 0};
+            void (*maps)(const double *, int64_t, const double *, const double *, const float *, int, int, int, int, int,
+                         double, const int32_t *, int, int, double *, int2 *, int64_t, const int32_t *, const int32_t *) =
+                ordered ? (dilate_ws ? disparity_maps_kernel<true, true> : disparity_maps_kernel<false, true>)
+                        : (dilate_ws ? disparity_maps_kernel<true, false> : disparity_maps_kernel<false, false>);
+            if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(maps), kMaxBandLds,
+                                                 &configured_m[2 * ordered + dilate_ws]))
+                return rc;
+            int2 *lists = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace) + plan.off_lists);
+            const ispa::TimingSlot timed = ispa::timing_begin(s);
+            hipLaunchKernelGGL(maps, dim3(n_map), dim3(kBandThreads), lds_ws, s, pts, n, cams1, cams2, depth,
+                               depth_per_map, H, W, ylim, xlim, relax, crop, crop_per_map, spread, flow, lists,
+                               (int64_t)disparity_wave_pitch(n), rank, inverse);
+            ispa::timing_end(timed, s);
+            return ispa::check_launch("disparity_maps_kernel");
+        }
         int32_t *counts = reinterpret_cast<int32_t *>(workspace);
         DisparityMapSetup *setup = reinterpret_cast<DisparityMapSetup *>(reinterpret_cast<char *>(workspace) + plan.off_setup);
         int2 *lists = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace) + plan.off_lists);
@@ -1007,14 +1178,3 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
     return ispa::check_launch("make_disparity_kernel");
 }
 }  // namespace
-
-#ifdef DISP_STAMP
-extern "C" int ispa_debug_stamps(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif

@@ -75,7 +75,7 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
     key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
     depth_maps (n_map,540,960) f32 (the first pose's depth image, used for both poses as the
     reference does); crop_params (n_map,4).  Only the first pose's truth masks the points.
-    fused=True runs the whole body in two launches without materialising projected coordinates
+    fused=True runs the whole body in one to three launches without materialising projected coordinates
     (ispa_make_disparity_ws; ispa_make_disparity is the one-launch form for callers without a workspace); fused=False goes through
     project_prune twice and flow_splat, materialising the projected coordinates like the reference.
     point_order: a PointOrder of key_3d (fused path only): the points are processed in its order, the results

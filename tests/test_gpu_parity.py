@@ -206,6 +206,40 @@ def test_make_disparity_golden(pea, golden_disparity, tag):
         assert np.array_equal(flow[0], z[f"{tag}_flow"])
 
 
+@pytest.mark.parametrize("ordered", [False, True])
+def test_make_disparity_one_workgroup_per_map(pea, ordered):
+    """A call with as many maps as the chip has compute units takes the kernel that gives each map a workgroup of
+    its own; the same maps in two calls of half the size take the kernels with per-band lists.  Same bytes, and
+    the oracle's flow for a few of the maps."""
+    import torch
+    maps = torch.cuda.get_device_properties(0).multi_processor_count
+    rs = np.random.RandomState(5)
+    n = 9000                                                   # three rounds of 4096 points, the last one ragged
+    pts = np.concatenate([pea.run_proj.sample_surface(*pea.run_proj.chair_mesh(), n - 2000, seed=2),
+                          rs.uniform(-0.4, 0.4, (2000, 3))])
+    params = np.stack([rs.uniform(0, 360, maps), rs.uniform(-10, 40, maps), rs.uniform(-5, 5, maps),
+                       rs.choice([2.6, 3.0], maps)], axis=1)
+    # depth "images": the camera distance plus a coarse random offset per texel block, so that visibility varies
+    coarse = torch.from_numpy(rs.uniform(-0.25, 0.25, (maps, 54, 96)).astype(np.float32)).cuda()
+    depth = torch.from_numpy(params[:, 3].astype(np.float32)).cuda()[:, None, None] + \
+        torch.repeat_interleave(torch.repeat_interleave(coarse, 10, dim=1), 10, dim=2)
+    crops = np.stack([rs.randint(60, 180, maps), rs.randint(330, 480, maps), rs.randint(250, 400, maps),
+                      rs.randint(560, 720, maps)], axis=1)
+    order = pea.disparity.PointOrder(pts) if ordered else None
+    pts_t = torch.from_numpy(pts).cuda()
+    whole = pea.disparity.make_disparity_maps(pts_t, params, depth, crops, point_order=order)
+    half = maps // 2
+    parts = [pea.disparity.make_disparity_maps(pts_t, params[a:b], depth[a:b], crops[a:b], point_order=order)
+             for a, b in ((0, half), (half, maps))]
+    assert torch.equal(whole, torch.cat(parts))
+    whole = whole.cpu().numpy()
+    depth_np = depth[:3].cpu().numpy()
+    for m in range(3):
+        want = odisp.make_disparity_core(pts, params[m].tolist(), depth_np[m], crops[m])
+        assert np.array_equal(whole[m], want)
+        assert np.count_nonzero(want) > 2000
+
+
 def test_make_disparity_batch_100k(pea):
     rs = np.random.RandomState(0)
     pts = rs.uniform(-0.4, 0.4, (100000, 3))
