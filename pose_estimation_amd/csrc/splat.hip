@@ -1137,14 +1137,14 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
         ISPA_HIP(hipGetDevice(&dev));
         ISPA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int rounds = (n_map + cus - 1) / std::max(cus, 1);
-        if (cus > 0 && (int64_t)n_map * 100 >= (int64_t)rounds * cus * 85) {
-            static unsigned long long configured_m[4] = {0, 0, 0, 0};
+        // (spreads of 1 to 4 only: the other spreads' pixel-by-pixel splat is not worth a second kernel)
+        if (dilate_ws && cus > 0 && (int64_t)n_map * 100 >= (int64_t)rounds * cus * 85) {
+            static unsigned long long configured_m[2] = {0, 0};
             void (*maps)(const double *, int64_t, const double *, const double *, const float *, int, int, int, int, int,
                          double, const int32_t *, int, int, double *, int2 *, int64_t, const int32_t *, const int32_t *) =
-                ordered ? (dilate_ws ? disparity_maps_kernel<true, true> : disparity_maps_kernel<false, true>)
-                        : (dilate_ws ? disparity_maps_kernel<true, false> : disparity_maps_kernel<false, false>);
+                ordered ? disparity_maps_kernel<true, true> : disparity_maps_kernel<true, false>;
             if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(maps), kMaxBandLds,
-                                                 &configured_m[2 * ordered + dilate_ws]))
+                                                 &configured_m[ordered]))
                 return rc;
             int2 *lists = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace) + plan.off_lists);
             const ispa::TimingSlot timed = ispa::timing_begin(s);

@@ -69,7 +69,7 @@ class PointOrder:
         self.inverse = dv.to_dev(inverse.astype(np.int32), torch.int32)
 
 
-def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, point_order=None):
+def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, point_order=None, spread=SPREAD):
     """Body of make_disparity for a batch of renders of ONE model.
 
     key_3d (N,3) surface samples; params (n_map,4) = [azimuth, elevation, tilt, rho] per render;
@@ -79,7 +79,7 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
     (ispa_make_disparity_ws; ispa_make_disparity is the one-launch form for callers without a workspace); fused=False goes through
     project_prune twice and flow_splat, materialising the projected coordinates like the reference.
     point_order: a PointOrder of key_3d (fused path only): the points are processed in its order, the results
-    are those of the given order.
+    are those of the given order.  spread: half the side of the block a point writes (2 in the script, line 63).
     Returns flow (n_map,224,224,2) float64, numpy unless key_3d is a device tensor."""
     as_tensor = dv.is_tensor(key_3d)
     if point_order is not None and (not fused or point_order.n != len(key_3d)):
@@ -113,7 +113,7 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
         _abi.check(_abi.lib.ispa_make_disparity_ordered(
             dv.ptr(po.points if po else pts), dv.ptr(po.rank) if po else None, dv.ptr(po.inverse) if po else None,
             pts.shape[0], dv.ptr(c1), dv.ptr(c2), n_map, dv.ptr(depth), 1 if depth.shape[0] > 1 else 0,
-            h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, SPREAD,
+            h, w, min(run_proj.VIS_YLIM, h), min(run_proj.VIS_XLIM, w), 0.15, dv.ptr(crop_t), 1, int(spread),
             dv.ptr(flow), dv.ptr(ws), need, dv.stream_ptr()))
         return dv.back(flow, as_tensor)
     if depth.shape[0] not in (1, n_map):
@@ -121,7 +121,7 @@ def make_disparity_maps(key_3d, params, depth_maps, crop_params, fused=True, poi
     shared = depth[0] if depth.shape[0] == 1 else depth       # a 2-D map is shared by all poses
     truth1, uv1 = run_proj.project_prune(pts, cams1, shared, crops)
     _, uv2 = run_proj.project_prune(pts, cams2, shared, crops)
-    flow = flow_splat(uv1, uv2, truth1)
+    flow = flow_splat(uv1, uv2, truth1, spread=int(spread))
     return dv.back(flow, as_tensor)
 
 

@@ -206,10 +206,11 @@ def test_make_disparity_golden(pea, golden_disparity, tag):
         assert np.array_equal(flow[0], z[f"{tag}_flow"])
 
 
-@pytest.mark.parametrize("ordered", [False, True])
-def test_make_disparity_one_workgroup_per_map(pea, ordered):
+@pytest.mark.parametrize("ordered,spread", [(False, 2), (True, 2), (True, 1), (False, 3), (True, 4), (False, 5), (True, 0)])
+def test_make_disparity_one_workgroup_per_map(pea, ordered, spread):
     """A call with as many maps as the chip has compute units takes the kernel that gives each map a workgroup of
-    its own; the same maps in two calls of half the size take the kernels with per-band lists.  Same bytes, and
+    its own (spreads 1 to 4); the same maps in two calls of half the size take the kernels with per-band lists.
+    Same bytes, the bytes of the path that materialises the projected coordinates, and (at the reference's spread)
     the oracle's flow for a few of the maps."""
     import torch
     maps = torch.cuda.get_device_properties(0).multi_processor_count
@@ -227,14 +228,15 @@ def test_make_disparity_one_workgroup_per_map(pea, ordered):
                       rs.randint(560, 720, maps)], axis=1)
     order = pea.disparity.PointOrder(pts) if ordered else None
     pts_t = torch.from_numpy(pts).cuda()
-    whole = pea.disparity.make_disparity_maps(pts_t, params, depth, crops, point_order=order)
+    whole = pea.disparity.make_disparity_maps(pts_t, params, depth, crops, point_order=order, spread=spread)
     half = maps // 2
-    parts = [pea.disparity.make_disparity_maps(pts_t, params[a:b], depth[a:b], crops[a:b], point_order=order)
-             for a, b in ((0, half), (half, maps))]
+    parts = [pea.disparity.make_disparity_maps(pts_t, params[a:b], depth[a:b], crops[a:b], point_order=order,
+                                               spread=spread) for a, b in ((0, half), (half, maps))]
     assert torch.equal(whole, torch.cat(parts))
+    assert torch.equal(whole, pea.disparity.make_disparity_maps(pts_t, params, depth, crops, fused=False, spread=spread))
     whole = whole.cpu().numpy()
     depth_np = depth[:3].cpu().numpy()
-    for m in range(3):
+    for m in range(3 if spread == 2 else 0):
         want = odisp.make_disparity_core(pts, params[m].tolist(), depth_np[m], crops[m])
         assert np.array_equal(whole[m], want)
         assert np.count_nonzero(want) > 2000
