@@ -698,65 +698,71 @@ __global__ __launch_bounds__(kBandThreads) void disparity_maps_kernel(
     int2 *mine = lists + ((int64_t)m * (kBandThreads / 64) + wave) * wave_pitch;
     int listed1 = 0;                                  // entries in this wave's list (uniform)
     constexpr int kBatch = 4;                         // loads, then gathers, of four points in flight together
-    double nx[kBatch], ny[kBatch], nz[kBatch];        // the next round's points travel during this round's work
-    int nrk[kBatch];
-    auto fetch = [&](int64_t first) {
+    // A round's depth texels are gathered one round ahead of their use: the visibility decision, the splat and
+    // the list entry of round r run after round r + 1's projections, so that the gather's latency is covered by
+    // this wave's own arithmetic (four waves per SIMD do not cover it for each other).
+    int c_word[kBatch], c_tag[kBatch];                // round r, waiting for its texels:
+    double c_z[kBatch];                               //   record if the point is kept, tag, depth at pose 1
+    float c_texel[kBatch];
+    bool c_pass[kBatch];                              //   inside the crop, inside the gate, a valid rank
+    auto finish = [&]() {
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const bool keep = c_pass[e] && depth_decide_a(true, c_z[e], c_texel[e], relax);
+            const int rec = keep ? c_word[e] : -1;
+            band_splat<DILATE>(owner, g, spread, rec, c_tag[e]);
+            // the rows a point writes lie in [iv - spread, iv + spread)
+            const bool second = rec >= 0 && (rec >> 16) + spread >= kDispBandRows;
+            const unsigned long long take = __builtin_amdgcn_ballot_w64(second);
+            if (second) mine[lanes_below(take, listed1)] = make_int2(rec, c_tag[e]);
+            listed1 += __popcll(take);
+        }
+    };
+    for (int64_t first = 0; first < n; first += kBandThreads * kBatch) {
         const int here = (int)min((int64_t)(kBandThreads * kBatch), n - first);
-        const double *pb = pts + 3 * first;
+        const double *pb = pts + 3 * first;           // this round's points: 32-bit offsets from a uniform base
         const int32_t *rb = rank ? rank + first : nullptr;
+        double px[kBatch], py[kBatch], pz[kBatch];
+        int rk[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const int l = (int)threadIdx.x + e * kBandThreads;
             const int j = l < here ? l : 0;
-            nx[e] = pb[3 * j];
-            ny[e] = pb[3 * j + 1];
-            nz[e] = pb[3 * j + 2];
-            nrk[e] = rb ? rb[j] : (int)first + j;
+            px[e] = pb[3 * j];
+            py[e] = pb[3 * j + 1];
+            pz[e] = pb[3 * j + 2];
+            rk[e] = rb ? rb[j] : (int)first + j;
         }
-    };
-    if (n > 0) fetch(0);
-    for (int64_t first = 0; first < n; first += kBandThreads * kBatch) {
-        const int here = (int)min((int64_t)(kBandThreads * kBatch), n - first);
-        double px[kBatch], py[kBatch], pz[kBatch];
-        int rk[kBatch], word[kBatch];
-#pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            px[e] = nx[e];
-            py[e] = ny[e];
-            pz[e] = nz[e];
-            rk[e] = nrk[e];
-        }
-        if (first + kBandThreads * kBatch < n) fetch(first + kBandThreads * kBatch);
-        bool ok[kBatch], gate[kBatch];
-        int at[kBatch];                               // H * W fits 31 bits (checked by the caller)
+        int word[kBatch], at[kBatch];                 // H * W fits 31 bits (checked by the caller)
+        bool pass[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             double u, v, z;
             project_point(P1, px[e], py[e], pz[e], u, v, z);
             pz[e] = z;
             double uc = u, vc = v;
-            ok[e] = crop_apply(cx, tall, 1, uc, vc);
+            const bool ok = crop_apply(cx, tall, 1, uc, vc);
             word[e] = (cvt_i32_sat(vc) << 16) | (cvt_i32_sat(uc) & 0xffff);
             const int gx = cvt_i32_sat(u), gy = cvt_i32_sat(v);   // pt2render.py:47-49
-            gate[e] = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
-            at[e] = gate[e] ? gy * W + gx : 0;
+            const bool gate = gy > 0 && gy < ylim && gx > 0 && gx < xlim;
+            at[e] = gate ? gy * W + gx : 0;
+            // a rank outside [0, n) drops its point (it can never own a pixel)
+            pass[e] = ok && gate && (int)threadIdx.x + e * kBandThreads < here && (unsigned)rk[e] < (unsigned)n;
         }
         float texel[kBatch];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) texel[e] = d[at[e]];
+        if (first > 0) finish();
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
-            const bool keep = ok[e] && depth_decide_a(gate[e], pz[e], texel[e], relax);
-            const bool listed = keep && (int)threadIdx.x + e * kBandThreads < here && (unsigned)rk[e] < (unsigned)n;
-            const int rec = listed ? word[e] : -1, tag = rk[e] + 1;
-            band_splat<DILATE>(owner, g, spread, rec, tag);
-            // the rows a point writes lie in [iv - spread, iv + spread)
-            const bool second = rec >= 0 && (rec >> 16) + spread >= kDispBandRows;
-            const unsigned long long take = __builtin_amdgcn_ballot_w64(second);
-            if (second) mine[lanes_below(take, listed1)] = make_int2(rec, tag);
-            listed1 += __popcll(take);
+            c_word[e] = word[e];
+            c_tag[e] = rk[e] + 1;
+            c_z[e] = pz[e];
+            c_texel[e] = texel[e];
+            c_pass[e] = pass[e];
         }
     }
+    if (n > 0) finish();
     __syncthreads();
     band_resolve<DILATE, ORDERED>(owner, g, spread, pts, n, P1, P2, cx, tall, out, inverse);
     // this wave's list, written above, is read back by the same wave: no wider scope is needed (a fence at
