@@ -48,6 +48,8 @@ sq nn___dtype_f32 --workload nn --dtype f32 &&
 sq nn___dtype_bf16 --workload nn --dtype bf16 &&
 sq nn___dtype_f32___filter_split --workload nn --dtype f32 --filter split &&
 sq zbuffer --workload zbuffer &&
+sq disparity --workload disparity &&
+sq2 disparity --workload disparity &&
 sq2 nn___dtype_bf16 --workload nn --dtype bf16 &&
 sq2 nn___dtype_f32 --workload nn --dtype f32 &&
 cd $R && { [ -n "$ONLY" ] || timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; } &&
