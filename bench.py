@@ -158,8 +158,9 @@ def measured_traffic(workload_key, kernel, is_default_shape):
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
         table = json.load(open(newest))[workload_key]
         src = os.path.relpath(newest, ROOT)
-        if "+" in kernel:                                # a timed pair of launches: their traffic adds up
-            return sum(table[k]["traffic_bytes"] for k in kernel.split("+")), src
+        if kernel.endswith("*"):                         # the timed launches of one call: their traffic adds up
+            hits = [v["traffic_bytes"] for k, v in table.items() if k.startswith(kernel[:-1])]
+            return (sum(hits), src) if hits else (None, None)
         if kernel in table:
             return table[kernel]["traffic_bytes"], src
         hits = [v["traffic_bytes"] for k, v in table.items() if k.startswith(kernel.replace("_kernel", ""))]
@@ -418,7 +419,7 @@ def run_geometry(args, torch, dist, world, rank, dev):
         {"project_prune": "project_prune2_kernel", "flow_band": "flow_band_kernel", "project": "project2_kernel",
          "zbuffer": "zbuffer_kernel", "zbuffer_tiled": "zb_tile_kernel", "corr_eccv": "corr_eccv_tile_kernel",
          "corr_acmm_gemm": "corr_acmm_gemm_kernel", "make_disparity": "make_disparity_kernel",
-         "make_disparity_ws": "disparity_points_kernel+disparity_bands_kernel"}[names[dom]],
+         "make_disparity_ws": "disparity_*"}[names[dom]],
         args.workload == "corr" or (n == 100000 and not sharded and
                                     (args.poses == 3600 if args.workload in ("project", "zbuffer") else args.maps == 256)))
     if traffic:

@@ -15,7 +15,7 @@ traffic = json.load(open(os.path.join(dst, f"{rnd}_pmc_traffic.json")))
 util = json.load(open(os.path.join(dst, f"{rnd}_pmc_mfma_util.json")))
 KERNEL = {"nn_filter": ("nn_filter",), "project_prune": ("project_prune2_kernel",), "zbuffer_tiled": ("zb_tile_kernel",),
           "zbuffer": ("zbuffer_kernel",), "project": ("project2_kernel",),
-          "make_disparity_ws": ("disparity_points_kernel", "disparity_bands_kernel"),
+          "make_disparity_ws": ("disparity_",),
           "corr_eccv": ("corr_eccv_tile_kernel",), "corr_acmm_gemm": ("corr_acmm_gemm_kernel",)}
 print("| bench command (`--workload ...`) | value | step ms | dominant kernel(s), traced avg | work per launch | achieved (traced) | frac of peak | counter HBM bytes | matrix-pipe busy |")
 print("|---|---|---|---|---|---|---|---|---|")
