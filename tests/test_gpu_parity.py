@@ -242,6 +242,57 @@ def test_make_disparity_one_workgroup_per_map(pea, ordered, spread):
         assert np.count_nonzero(want) > 2000
 
 
+def test_make_disparity_one_workgroup_per_map_bad_ranks_and_workspace(pea):
+    """The kernel with a workgroup per map through the C ABI: ranks and inverse entries outside [0, n) give the
+    maps of the kernels with lists (points dropped, pixels left empty, nothing faults); a workspace that is too
+    small or not 8-byte aligned is refused; a single point and no point at all work."""
+    import torch
+    from pose_estimation_amd import _abi, _device as dv
+    maps = torch.cuda.get_device_properties(0).multi_processor_count
+    rs = np.random.RandomState(11)
+    n = 5000
+    pts = pea.run_proj.sample_surface(*pea.run_proj.chair_mesh(), n, seed=4)
+    params = np.stack([rs.uniform(0, 360, maps), rs.uniform(-10, 40, maps), np.zeros(maps), np.full(maps, 3.0)], axis=1)
+    more = params.copy()
+    more[:, :2] += 10
+    cams1 = dv.to_dev(pea.pt2render.camera_matrices(params), torch.float64)
+    cams2 = dv.to_dev(pea.pt2render.camera_matrices(more), torch.float64)
+    depth = torch.full((1, 540, 960), 3.0, dtype=torch.float32, device="cuda")
+    crops = dv.to_dev(np.tile(np.array([[100, 400, 300, 700]]), (maps, 1)), torch.int32)
+    order = pea.disparity.PointOrder(pts)
+    rank = order.rank.clone()
+    rank[::7] = n + 5
+    rank[3::7] = -2
+    inv = order.inverse.clone()
+    inv[::5] = n
+    inv[2::5] = -1
+
+    def call(first, count, ws, need, points=order.points, n_=n, rk=rank, iv=inv):
+        flow = torch.full((count, 224, 224, 2), np.nan, dtype=torch.float64, device="cuda")
+        rc = _abi.lib.ispa_make_disparity_ordered(
+            dv.ptr(points), dv.ptr(rk) if rk is not None else None, dv.ptr(iv) if iv is not None else None, n_,
+            dv.ptr(cams1[first:]), dv.ptr(cams2[first:]), count, dv.ptr(depth), 0, 540, 960, 540, 950, 0.15,
+            dv.ptr(crops[first:]), 1, 2, dv.ptr(flow), dv.ptr(ws) if ws is not None else None, need, dv.stream_ptr())
+        torch.cuda.synchronize()
+        return rc, flow
+
+    need = _abi.lib.ispa_make_disparity_workspace_bytes(n, maps)
+    ws = dv.empty((need + 8,), torch.uint8)
+    rc, whole = call(0, maps, ws, need)
+    assert rc == 0 and torch.isfinite(whole).all() and torch.count_nonzero(whole) > 1000 * maps
+    half = maps // 2
+    parts = [call(a, b - a, ws, need)[1] for a, b in ((0, half), (half, maps))]
+    assert torch.equal(whole, torch.cat(parts))
+    assert call(0, maps, ws, need - 1)[0] == -3                       # ISPA_EWORKSPACE
+    assert call(0, maps, ws[4:], need)[0] == -1                       # not 8-byte aligned
+    # one point; no point (every map empty)
+    one = dv.to_dev(pts[:1], torch.float64)
+    rc, flow1 = call(0, maps, ws, need, points=one, n_=1, rk=None, iv=None)
+    assert rc == 0 and torch.isfinite(flow1).all()
+    rc, flow0 = call(0, maps, ws, need, points=one, n_=0, rk=None, iv=None)
+    assert rc == 0 and torch.count_nonzero(flow0) == 0
+
+
 def test_make_disparity_batch_100k(pea):
     rs = np.random.RandomState(0)
     pts = rs.uniform(-0.4, 0.4, (100000, 3))
