@@ -338,6 +338,7 @@ constexpr int kPointsPerThread = DISP_PPT;    // per map: amortises the crop tra
 constexpr int kDispBandRows = kBandPixels / (int)ispa_geom::kCropSide;
 constexpr int kDispBands = ((int)ispa_geom::kCropSide + kDispBandRows - 1) / kDispBandRows;
 constexpr int kResolveChunk = 4;             // x 64 pixels per wave between two queue drains
+constexpr int kMapRoundPoints = 4;           // points per thread and round of disparity_maps_kernel
 constexpr size_t kResolveQueueBytes = (size_t)kBandThreads * kResolveChunk * sizeof(int2) + 8;
 // base + the number of lanes below this one whose bit is set in `mask`
 __device__ __forceinline__ int lanes_below(unsigned long long mask, int base) {
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(kBandThreads) void disparity_maps_kernel(
     __syncthreads();
     int2 *mine = lists + ((int64_t)m * (kBandThreads / 64) + wave) * wave_pitch;
     int listed1 = 0;                                  // entries in this wave's list (uniform)
-    constexpr int kBatch = 4;                         // loads, then gathers, of four points in flight together
+    constexpr int kBatch = kMapRoundPoints;           // loads, then gathers, of four points in flight together
     // A round's depth texels are gathered one round ahead of their use: the visibility decision, the splat and
     // the list entry of round r run after round r + 1's projections, so that the gather's latency is covered by
     // this wave's own arithmetic (four waves per SIMD do not cover it for each other).
@@ -1034,9 +1035,10 @@ int make_disparity_impl(const double *pts, int64_t n, const double *cams1, const
                         const int32_t *rank = nullptr, const int32_t *inverse = nullptr);
 }
 
-// entries a wave of disparity_maps_kernel can list: 4 x 64 per round of 4 x 1024 points
+// entries a wave of disparity_maps_kernel can list: one per lane and point of a round
 static size_t disparity_wave_pitch(int64_t n) {
-    return (size_t)((n + 4 * kBandThreads - 1) / (4 * kBandThreads)) * 256;
+    constexpr int64_t round = (int64_t)kMapRoundPoints * kBandThreads;
+    return (size_t)((n + round - 1) / round) * (64 * kMapRoundPoints);
 }
 // workspace of the paths with lists: their lengths per (map, band), the per-map set-up, then the lists themselves
 // at their worst-case size
