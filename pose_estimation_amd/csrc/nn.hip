@@ -11,7 +11,7 @@
 //                 stream; the Nq x Nr score matrix never leaves the register file.  Variants:
 //                 2a  float32 MFMA, tiles staged in LDS (any k, any C, converting loader for odd shapes)
 //                 2a' float32 MFMA, query fragments resident in registers (top-1, C <= 128)
-//                 2b  bfloat16 32x32x16 MFMA (k > 1, C <= 256)
+//                 2b  bfloat16 32x32x16 MFMA (k > 1, C <= 256; any k for 256 < C <= 512, multiples of 64)
 //                 2c  bfloat16 16x16x32 MFMA, tagged top-1 (C <= 256)
 //                 2d  float32 inputs as a bfloat16 hi/lo split on the 16x16x32 MFMA (top-1, C <= 128)
 //   3. finalize   merges the partial streams; a query whose consecutive score gaps all exceed
@@ -29,6 +29,7 @@
 #include "nn_lists.h"         //     running top lists of the filter kernels
 #include "nn_filter_f32.h"    // 2a  float32 MFMA filters
 #include "nn_filter_bf16.h"   // 2b  bfloat16 32x32x16 filter (any k)
+#include "nn_filter_bf16_wide.h"   // 2b' the same for 257 to 512 channels
 #include "nn_filter_t16.h"    // 2c  bfloat16 16x16x32 top-1 filter
 #include "nn_filter_split.h"  // 2d  split-bfloat16 top-1 filter for float32 inputs
 #include "nn_finalize.h"      // 3.  finalize, re-scoring, refinement
@@ -59,11 +60,11 @@ Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k)
     const int dtype = dtype_and_flags & ~ISPA_NN_NORMALIZE;
     p.normalize = (dtype_and_flags & ISPA_NN_NORMALIZE) != 0 && dtype != ISPA_BF16;
     const bool fast_shape = C % 32 == 0 && nq % 8 == 0 && nr % 8 == 0 && nr < (1 << 27);   // 32-bit lane offsets
-    p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && C <= 256;
+    p.bf16_mfma = dtype == ISPA_BF16 && fast_shape && (C <= 256 || (C <= 512 && C % 64 == 0));
     p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 256 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
     const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
-    p.t16 = p.bf16_mfma && k == 1 && !ISPA_TOP1_32X32;          // top-1: the 16x16x32 kernel
+    p.t16 = p.bf16_mfma && k == 1 && C <= 256 && !ISPA_TOP1_32X32;   // top-1: the 16x16x32 kernel
     const int substreams =
         (p.t16 || p.split) ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
@@ -152,6 +153,30 @@ int launch_bf16(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, 
     hipLaunchKernelGGL((nn_filter_bf16_kernel<KS, KT, QT>), grid, dim3(512 / QT), lds_bytes, s, q, r, rnh, nq, nr,
                        p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, qnh_out, q64_out);
     return ISPA_OK;
+}
+
+template <int KS, int KT>
+int launch_bf16_wide(dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh, int64_t nq,
+                     int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out, double *q64_out) {
+    constexpr int lds_bytes = bf16_wide_lds_bytes<KS>();
+    static unsigned long long configured = 0;       // per instantiation, one bit per device
+    if (int rc = ispa::allow_dynamic_lds(reinterpret_cast<const void *>(&nn_filter_bf16_wide_kernel<KS, KT>), lds_bytes,
+                                         &configured))
+        return rc;
+    hipLaunchKernelGGL((nn_filter_bf16_wide_kernel<KS, KT>), grid, dim3(512), lds_bytes, s, q, r, rnh, nq, nr,
+                       p.n_qtiles, p.nsplit, p.refs_per_split, pval, pidx, qnh_out, q64_out);
+    return ISPA_OK;
+}
+template <int KT>
+int launch_bf16_wide_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, const uint16_t *r, const float *rnh,
+                        int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out,
+                        double *q64_out) {
+    switch (ks) {
+        case 20: return launch_bf16_wide<20, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 24: return launch_bf16_wide<24, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 28: return launch_bf16_wide<28, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        default: return launch_bf16_wide<32, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+    }
 }
 
 #ifndef ISPA_T16_NQ
@@ -338,7 +363,11 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr
         tag_rel = p.ktemplate == 1 ? kTag4 : kTag7;
         const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
         int rc;
-        if (p.t16) {
+        if (C > 256) {
+            if (p.ktemplate == 1) rc = launch_bf16_wide_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
+            else if (p.ktemplate == 5) rc = launch_bf16_wide_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
+            else rc = launch_bf16_wide_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
+        } else if (p.t16) {
             switch (C / 32) {
                 case 1: rc = launch_t16<1>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
                 case 2: rc = launch_t16<2>(grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64); break;
@@ -494,10 +523,12 @@ PadPlan make_pad_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr,
     const int inner_flags = dtype_and_flags & ISPA_NN_NORMALIZE;
     const size_t elem = dtype == ISPA_BF16 ? 2 : 4;
     pp.Cp = (C + 31) / 32 * 32;
+    // the bfloat16 kernels take multiples of 64 channels above 256
+    if (dtype == ISPA_BF16 && pp.Cp > 256) pp.Cp = (C + 63) / 64 * 64;
     pp.nqp = (nq + 7) / 8 * 8;
     pp.nrp = (nr + 7) / 8 * 8;
-    // bfloat16 beyond 256 channels runs through the converting float32 loader whatever the shape
-    const bool reachable = dtype == ISPA_BF16 ? pp.Cp <= 256 : true;
+    // bfloat16 beyond 512 channels runs through the converting float32 loader whatever the shape
+    const bool reachable = dtype == ISPA_BF16 ? pp.Cp <= 512 : true;
     pp.on = !(dtype_and_flags & ISPA_NN_NO_PAD) && reachable && nr >= k && pp.nrp < (1 << 27) &&
             (pp.Cp != C || pp.nqp != nq || pp.nrp != nr);
     if (!pp.on) {

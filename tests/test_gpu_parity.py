@@ -1053,6 +1053,40 @@ def test_nn_bf16_shapes_and_error_model(pea):
                 assert worst <= 0.5, worst
 
 
+def test_nn_bf16_257_to_512_channels(pea):
+    """bfloat16 maps of more than 256 channels take the kernel with a two-image ring (multiples of 64 channels up
+    to 512; other counts are padded inside the call): every k template, ragged tiles, split reference ranges, one
+    chunk, the padded counts, and the same counts through the guarded loaders (pad=False)."""
+    import torch
+    rs = np.random.RandomState(97)
+    for c in (320, 384, 448, 512):
+        _nn_check(pea, _unit(rs, (2, c, 264)), _unit(rs, (2, c, 1032)), 1, bf16=True)
+        _nn_check(pea, _unit(rs, (1, c, 520)), _unit(rs, (1, c, 776)), 5, bf16=True)
+    _nn_check(pea, _unit(rs, (1, 512, 1024)), _unit(rs, (1, 512, 4096)), 8, bf16=True)
+    _nn_check(pea, _unit(rs, (3, 384, 8)), _unit(rs, (3, 384, 64)), 1, bf16=True)        # one chunk
+    _nn_check(pea, _unit(rs, (1, 320, 40)), _unit(rs, (1, 320, 8200)), 5, bf16=True)     # many splits
+    for c in (260, 300, 450):                                                            # padded to 320 / 320 / 512
+        _nn_check(pea, _unit(rs, (2, c, 100)), _unit(rs, (2, c, 333)), 1, bf16=True)
+        _nn_check(pea, _unit(rs, (1, c, 129)), _unit(rs, (1, c, 515)), 5, bf16=True)
+    # duplicates and a run of identical references across a chunk boundary: lowest index wins
+    q = _unit(rs, (1, 512, 256))
+    r = _unit(rs, (1, 512, 1024))
+    r[0, :, 60:70] = r[0, :, 59:60]
+    r[0, :, 900] = r[0, :, 3]
+    q[0, :, 5] = r[0, :, 3]
+    q[0, :, 6] = r[0, :, 65]
+    _nn_check(pea, q, r, 1, bf16=True)
+    _nn_check(pea, q, r, 5, bf16=True)
+    # the same maps through the guarded loaders: same indices, same distance bits
+    qd = torch.from_numpy(_unit(rs, (2, 300, 264))).cuda().to(torch.bfloat16)
+    rd = torch.from_numpy(_unit(rs, (2, 300, 1032))).cuda().to(torch.bfloat16)
+    for k in (1, 5):
+        d1, i1 = pea.correspondence.dense_nn(qd, rd, k)
+        d2, i2 = pea.correspondence.dense_nn(qd, rd, k, pad=False)
+        assert torch.equal(i1, i2)
+        assert torch.allclose(d1, d2, rtol=1e-4, atol=1e-6)
+
+
 def test_nn_bf16_against_float32_oracle(pea):
     """bfloat16 features vs the float32 oracle on the unrounded features: wherever the float32 margin
     (d2 - d1) / max(d1, 1e-6) exceeds 2^-7 the nearest neighbour must be the same; distances within

@@ -39,7 +39,7 @@ def main():
     rs = np.random.RandomState(seed)
     t0, cases = time.time(), 0
     while time.time() - t0 < budget:
-        c = int(rs.choice([8, 32, 64, 96, 128, 192, 256]))
+        c = int(rs.choice([8, 32, 64, 96, 128, 192, 256, 320, 384, 512]))
         k = int(rs.choice([1, 1, 2, 5, 5, 8]))
         mode = str(rs.choice(["f32", "bf16", "bf16", "split"]))
         big = rs.rand() < 0.25
@@ -49,7 +49,7 @@ def main():
         if rs.rand() < 0.3:                               # shapes off the grid of the fast kernels
             nq += int(rs.randint(0, 8))
             nr += int(rs.randint(0, 8))
-            c = int(rs.choice([c, 20, 48, 100, 144]))
+            c = int(rs.choice([c, 20, 48, 100, 144, 300, 450]))
         pad = bool(rs.rand() < 0.7)                       # host-side padding up to the grid, or the library's guarded loaders
         style = int(rs.randint(0, 4))
         if style == 0:                                    # random unit vectors

@@ -12,7 +12,7 @@ b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 g = torch.Generator(device="cuda").manual_seed(5)
 print(f"{b} pairs of 64x64 maps; TFLOP/s of 2 nq nr C per pair over the whole call")
 print("   C   k " + " ".join(f"{m:>12s}" for m in ("f32", "bf16", "f32-split")))
-for c in (32, 64, 96, 128, 160, 192, 224, 256, 288, 100):
+for c in (32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 384, 512, 100):
     x = torch.randn(2, b, c, 4096, device="cuda", generator=g)
     x = x / x.norm(dim=2, keepdim=True)
     for k in (1, 5, 8):
