@@ -11,7 +11,8 @@
 //                 stream; the Nq x Nr score matrix never leaves the register file.  Variants:
 //                 2a  float32 MFMA, tiles staged in LDS (any k, any C, converting loader for odd shapes)
 //                 2a' float32 MFMA, query fragments resident in registers (top-1, C <= 128)
-//                 2b  bfloat16 32x32x16 MFMA (k > 1, C <= 256; any k for 256 < C <= 512, multiples of 64)
+//                 2b  bfloat16 32x32x16 MFMA (k > 1, C <= 256)
+//                 2b' the same with a two-image ring (any k; C = 192, 256, ..., 512)
 //                 2c  bfloat16 16x16x32 MFMA, tagged top-1 (C <= 256)
 //                 2d  float32 inputs as a bfloat16 hi/lo split on the 16x16x32 MFMA (top-1, C <= 128)
 //   3. finalize   merges the partial streams; a query whose consecutive score gaps all exceed
@@ -29,7 +30,7 @@
 #include "nn_lists.h"         //     running top lists of the filter kernels
 #include "nn_filter_f32.h"    // 2a  float32 MFMA filters
 #include "nn_filter_bf16.h"   // 2b  bfloat16 32x32x16 filter (any k)
-#include "nn_filter_bf16_wide.h"   // 2b' the same for 257 to 512 channels
+#include "nn_filter_bf16_wide.h"   // 2b' the same for 192 to 512 channels in multiples of 64
 #include "nn_filter_t16.h"    // 2c  bfloat16 16x16x32 top-1 filter
 #include "nn_filter_split.h"  // 2d  split-bfloat16 top-1 filter for float32 inputs
 #include "nn_finalize.h"      // 3.  finalize, re-scoring, refinement
@@ -55,6 +56,10 @@ struct Plan {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Channel counts of nn_filter_bf16_wide_kernel: multiples of 64 from 192 on (measured against the kernels with a
+// three-image ring at 192 and 256 channels: top-1 1.29x / 1.13x the speed, top-5 and top-8 1.02-1.04x)
+inline bool bf16_wide_shape(int C) { return C >= 192 && C <= 512 && C % 64 == 0; }
+
 Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k) {
     Plan p;
     const int dtype = dtype_and_flags & ~ISPA_NN_NORMALIZE;
@@ -64,7 +69,7 @@ Plan make_plan(int dtype_and_flags, int B, int C, int64_t nq, int64_t nr, int k)
     p.split = dtype == ISPA_F32_SPLIT && fast_shape && C <= 256 && k == 1;
     p.tq = p.split ? kSQ : (p.bf16_mfma ? kBQ : kTQ);
     const int chunk_refs = (p.bf16_mfma || p.split) ? kBR : kTR;
-    p.t16 = p.bf16_mfma && k == 1 && C <= 256 && !ISPA_TOP1_32X32;   // top-1: the 16x16x32 kernel
+    p.t16 = p.bf16_mfma && k == 1 && !bf16_wide_shape(C) && !ISPA_TOP1_32X32;   // top-1: the 16x16x32 kernel
     const int substreams =
         (p.t16 || p.split) ? kT16SubStreams : (p.bf16_mfma ? kBSubStreams : kSubStreams);
     p.n_qtiles = (int)((nq + p.tq - 1) / p.tq);
@@ -172,6 +177,8 @@ int launch_bf16_wide_ks(int ks, dim3 grid, hipStream_t s, const uint16_t *q, con
                         int64_t nq, int64_t nr, const Plan &p, float *pval, int *pidx, float *qnh_out,
                         double *q64_out) {
     switch (ks) {
+        case 12: return launch_bf16_wide<12, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
+        case 16: return launch_bf16_wide<16, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
         case 20: return launch_bf16_wide<20, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
         case 24: return launch_bf16_wide<24, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
         case 28: return launch_bf16_wide<28, KT>(grid, s, q, r, rnh, nq, nr, p, pval, pidx, qnh_out, q64_out);
@@ -363,7 +370,7 @@ int run(const T *q, const T *r, int B, int C, int64_t nq, int64_t nr, int64_t nr
         tag_rel = p.ktemplate == 1 ? kTag4 : kTag7;
         const uint16_t *qh = reinterpret_cast<const uint16_t *>(q), *rh = reinterpret_cast<const uint16_t *>(r);
         int rc;
-        if (C > 256) {
+        if (bf16_wide_shape(C)) {
             if (p.ktemplate == 1) rc = launch_bf16_wide_ks<1>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
             else if (p.ktemplate == 5) rc = launch_bf16_wide_ks<5>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);
             else rc = launch_bf16_wide_ks<kMaxK>(C / 16, grid, s, qh, rh, rnh, nq, nr, p, pval, pidx, fq_nh, fq_64);

@@ -1,23 +1,25 @@
-// Dense nearest neighbour, pass 2b': the bfloat16 32x32x16 MFMA filter for 257 to 512 channels (included by nn.hip).
+// Dense nearest neighbour, pass 2b': the bfloat16 32x32x16 MFMA filter for 192 to 512 channels (included by nn.hip).
 #pragma once
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// 2b'. filter pass, bfloat16 MFMA, more than 256 channels (multiples of 64 up to 512), any k
+// 2b'. filter pass, bfloat16 MFMA, 192 to 512 channels in multiples of 64, any k
 //
-// The scheme of nn_filter_bf16_kernel with what the sizes force: the query fragments of a wave's 32 queries
-// take C / 4 registers (128 at 512 channels), so a 512-thread workgroup (8 waves of 32 queries, two to a SIMD)
-// owns the CU; the query tile goes through LDS in two halves of up to 256 channels (a 256-query tile of 512
-// channels is 288 KiB); a 64-reference chunk image is up to 64 KiB, so the ring holds TWO of them and the
-// workgroup meets at the start of every chunk: chunk c + 1 is fetched (LDS-direct) while chunk c is
+// The scheme of nn_filter_bf16_kernel with what more than 256 channels force: the query fragments of a wave's
+// 32 queries take C / 4 registers (128 at 512 channels), so a 512-thread workgroup (8 waves of 32 queries, two
+// to a SIMD) owns the CU; the query tile goes through LDS in two halves of up to 256 channels (a 256-query tile
+// of 512 channels is 288 KiB); a 64-reference chunk image is up to 64 KiB, so the ring holds TWO of them and
+// the workgroup meets at the start of every chunk: chunk c + 1 is fetched (LDS-direct) while chunk c is
 // contracted, and no fragment is read across a chunk boundary.  Same lists, same partial streams, same
-// finalize as the kernel for up to 256 channels.
+// finalize as the kernel for up to 256 channels.  With 12 and more MFMAs per 32x32 tile the list update is a
+// small share of a chunk and one barrier per chunk is cheap: at 192 and 256 channels this kernel is also the
+// faster one (top-1 on the 32x32x16 shape included), so those counts come here too.
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 constexpr int bf16_wide_lds_bytes() {
     constexpr int ring = 2 * 16 * KS * kRStride + 2 * kBR * (int)sizeof(float);
-    constexpr int qimage = 256 * kQStride;
+    constexpr int qimage = (16 * KS < 256 ? 16 * KS : 256) * kQStride;
     return ring > qimage ? ring : qimage;
 }
 
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(512, 1) void nn_filter_bf16_wide_kernel(
     constexpr int kRBuf = C * kRStride;                 // one reference chunk image
     constexpr int kNT = 512;                            // threads
     constexpr int kSeg = KS / 4;                        // 1 KiB pieces of a chunk image per wave
-    static_assert(KS % 4 == 0 && KS > 16 && KS <= 32, "C must be a multiple of 64 above 256, at most 512");
+    static_assert(KS % 4 == 0 && KS >= 12 && KS <= 32, "C must be a multiple of 64 from 192 to 512");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *rbuf = lds;                                   // ring of 2 chunk images
     float *nhbuf = reinterpret_cast<float *>(lds + 2 * kRBuf);   // ring of 2 x kBR floats
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(512, 1) void nn_filter_bf16_wide_kernel(
     double qsum = 0.0;
     static_for<0, 2>([&](auto ih) {
         constexpr int half = decltype(ih)::value;
-        constexpr int rows = half == 0 ? 256 : C - 256;
+        constexpr int rows = half == 0 ? (C < 256 ? C : 256) : (C > 256 ? C - 256 : 0);
         if (half) __syncthreads();                       // the first half's image is no longer needed
 #pragma unroll
         for (int e = 0; e < rows / 16; ++e) {            // rows x 32 segments of 8 queries
