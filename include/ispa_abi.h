@@ -57,8 +57,8 @@ enum { ISPA_F32 = 0, ISPA_BF16 = 1, ISPA_F32_SPLIT = 2, ISPA_F32_SPLIT_ALWAYS = 
  * live in the workspace (ask ispa_nn_workspace_bytes_for with the flag set). */
 enum { ISPA_NN_NORMALIZE = 256 };
 /* OR'ed into the dtype of ispa_nn_topk: hand the arrays to the kernels as they are.  Without it a call whose
- * channel count is not a multiple of 32 or whose cell counts are not multiples of 8 (the grid of the MFMA
- * filters: 16-byte rows) is brought onto that grid inside the call, in the workspace - zero channels, copies
+ * channel count is not a multiple of 32 (bfloat16 above 256 channels: of 64, up to 512) or whose cell counts
+ * are not multiples of 8 (the grid of the MFMA filters: 16-byte rows) is brought onto that grid inside the call, in the workspace - zero channels, copies
  * of the last query column whose results are dropped, reference cells that no query can select, for any k -
  * with the same results as the guarded loaders this flag selects (tests, timing). */
 enum { ISPA_NN_NO_PAD = 512 };
